@@ -1,0 +1,125 @@
+"""CPU: the numpy oracle against the golden vectors the REFERENCE produced
+(tests/golden/make_golden.py).  This is what pins the oracle before anything on
+the GPU is compared with it."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import gnode_oracle as O
+
+RTOL = 1e-5   # north_star: 1e-5 relative fp32
+
+
+def _load(path):
+    d = dict(np.load(path))
+    P = {k[2:]: d[k] for k in d if k.startswith("P:")}
+    return d, P
+
+
+def _close(a, b, rtol=RTOL, atol=None):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = np.max(np.abs(b)) + 1e-30
+    err = np.max(np.abs(a - b)) / scale
+    assert err <= rtol, f"max rel-to-scale err {err:.3e} > {rtol}"
+
+
+def _cases(prefix, golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
+    return sorted(glob.glob(os.path.join(golden_dir, prefix + "*.npz")))
+
+
+@pytest.mark.parametrize("path", _cases("rhs_single_"), ids=os.path.basename)
+def test_rhs_single_matches_reference(path):
+    d, P = _load(path)
+    rp, ci = O.csr_from_edges(int(d["n"]), d["edges"])
+    dx = O.rhs_single(d["x"], P["odefunc.linear.weight"], P["odefunc.linear.bias"], rp, ci, int(d["n"]))
+    assert dx.shape == d["dx"].shape and dx.dtype == np.float32
+    _close(dx, d["dx"])
+    q = dx.shape[0] // 4
+    assert not dx[3 * q:].any()                      # 4th slab derivative is exactly 0
+
+
+@pytest.mark.parametrize("path", _cases("fwd_single_"), ids=os.path.basename)
+def test_forward_single_matches_reference(path):
+    d, P = _load(path)
+    rp, ci = O.csr_from_edges(int(d["n"]), d["edges"])
+    S, I, R = O.odeblock_forward_single(d["x"], P, rp, ci, int(d["maxTime"]), float(d["deltaT"]))
+    for got, want in ((S, d["S"]), (I, d["I"]), (R, d["R"])):
+        assert got.shape == want.shape
+        _close(got, want)
+    np.testing.assert_allclose(S + I + R, 1.0, atol=1e-6)
+    sub = O.get_sir_t_nodes(S[..., 0], int(d["maxTime"]), float(d["deltaT"]))
+    _close(sub, d["S_sub"])
+    if "loss" in d:
+        loss = O.l1_loss(S, I, R, d["y"], int(d["maxTime"]), float(d["deltaT"]))
+        assert abs(loss - float(d["loss"])) <= 1e-6
+
+
+@pytest.mark.parametrize("path", _cases("multi_"), ids=os.path.basename)
+def test_multi_graph_matches_reference(path):
+    d, P = _load(path)
+    graphs = [O.csr_from_edges(int(d[f"n{j}"]), d[f"edges{j}"]) for j in range(3)]
+    dst = O.rhs_multi(d["state"], P["odefunc.linear.weight"], P["odefunc.linear.bias"], graphs)
+    _close(dst, d["dstate"])
+    S, I, R = O.odeblock_forward_multi(d["x"], P, graphs, int(d["maxTime"]), float(d["deltaT"]))
+    for got, want in ((S, d["S"]), (I, d["I"]), (R, d["R"])):
+        assert got.shape == want.shape
+        _close(got, want)
+
+
+@pytest.mark.parametrize("path", _cases("sir_"), ids=os.path.basename)
+def test_sir_coin_stream_is_bit_exact(path):
+    d, _ = _load(path)
+    table = O.edge_table(d["edges"])
+    S, I, R, used, trace = O.sir_coins(int(d["n"]), table, d["seeds"].tolist(), float(d["beta"]), float(d["gamma"]),
+                                       int(d["sims"]), int(d["T"]), d["coins"])
+    assert used == d["coins"].shape[0]               # consumed exactly the coins the reference drew
+    for got, want in ((S, d["S"]), (I, d["I"]), (R, d["R"])):
+        assert got.shape == want.shape
+        assert np.array_equal(got, want)             # integer counts: bit-exact
+
+
+def test_sir_philox_statistics_match_coin_model():
+    """The production coin source changes only WHICH uniform numbers are drawn:
+    means of many sims must agree with the reference-stream model within MC error."""
+    d, _ = _load(_cases("sir_karate")[0])
+    n = int(d["n"])
+    rp, ci = O.csr_from_edges(n, d["edges"])
+    sims, T = 3000, 12
+    seeds, beta, gamma = d["seeds"].tolist(), float(d["beta"]), float(d["gamma"])
+    cnt = O.sir_philox(n, rp, ci, seeds, beta, gamma, sims, T, rng_seed=1234)
+    rng = np.random.default_rng(0)
+    S, I, R, _, _ = O.sir_coins(n, O.edge_table(d["edges"]), seeds, beta, gamma, sims, T, rng.random(10_000_000))
+    a = cnt[:, 1:, :].astype(np.float64) / sims
+    b = np.stack([S[0], I[0], R[0]])[:, 1:, :] / sims
+    assert np.max(np.abs(a - b)) < 0.06 and np.mean(np.abs(a - b)) < 0.012
+    assert np.array_equal(cnt[0, 1:] + cnt[1, 1:] + cnt[2, 1:], np.full((T - 1, n), sims, dtype=np.uint32))
+
+
+def test_sir_philox_sharding_is_exact():
+    n = 34
+    d, _ = _load(_cases("sir_karate")[0])
+    rp, ci = O.csr_from_edges(n, d["edges"])
+    whole = O.sir_philox(n, rp, ci, [0, 33], 0.3, 0.2, 40, 10, rng_seed=99)
+    a = O.sir_philox(n, rp, ci, [0, 33], 0.3, 0.2, 25, 10, rng_seed=99, sim_offset=0)
+    b = O.sir_philox(n, rp, ci, [0, 33], 0.3, 0.2, 15, 10, rng_seed=99, sim_offset=25)
+    merged = a + b
+    merged[:2, 0] = whole[:2, 0]                      # row 0 is assigned, not accumulated (Q3)
+    assert np.array_equal(merged, whole)
+
+
+def test_philox_known_answer():
+    """Random123 known-answer vectors for philox4x32-10."""
+    assert int(O.philox4x32_10(0, 0, 0, 0, 0, 0)) == 0x6627E8D5
+    assert int(O.philox4x32_10(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)) == 0x408F276D
+    assert int(O.philox4x32_10(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0)) == 0xD16CFE09
+
+
+def test_er_graph_contract():
+    rp, ci, e = O.er_graph(500, 2000, seed=0)
+    assert e.shape == (2000, 2) and ci.shape[0] == 4000 and rp[-1] == 4000
+    assert np.all(e[:, 0] != e[:, 1])
+    for r in range(500):
+        seg = ci[rp[r]:rp[r + 1]]
+        assert np.all(np.diff(seg) > 0)
