@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""GN-ODE forward benchmark: node-timesteps/s on the 75k-node Erdos-Renyi workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one ODEBlock.forward (encoder + 59 Euler steps + read-out at every
+grid point) over this rank's batch of 8 (beta, gamma, seed-set) samples on the
+75 000-node / 500 000-edge graph, H = 64, maxTime = 30, deltaT = 0.5
+(BASELINE.json configs[3]).  Samples shard across ranks with no
+data-path collective (weak scaling: 8 samples per GPU); the only collectives are
+the barrier and the MAX of the elapsed time.  Inputs are resident in HBM before
+the timed region starts.
+
+value = ranks * samples_per_rank * N * n_euler_steps * K / max-over-ranks seconds.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "gn-ode-sir_amd"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_sample_step(n, nnz, H):
+    """Dominant kernel (CSR pull-gather + SIR derivative + Euler update + read-out), one
+    sample, one Euler step, fp32 / int32 CSR (DESIGN.md "Kernels"):
+    col nnz*4 + rowptr (n+1)*4 + neighbour rows nnz*H*4   (the edge-gather step)
+    + own Z_S, Z_I rows 2*n*H*4 + state read 3*n*H*4 + state write 3*n*H*4."""
+    return nnz * 4 + (n + 1) * 4 + nnz * H * 4 + 8 * n * H * 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nodes", type=int, default=75000)
+    ap.add_argument("--edges", type=int, default=500000)
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--samples", type=int, default=8, help="samples per GPU")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("GNODE_CHUNK", "1")),
+                    help="samples integrated together per launch sequence")
+    ap.add_argument("--maxTime", type=int, default=30)
+    ap.add_argument("--deltaT", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=12, help="Euler steps of the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the GN-ODE path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import gnode_oracle as O
+    from gnode import _lib, ops
+    from gnode.graph import DeviceGraph
+
+    lib = _lib.load()
+    n, H, B = args.nodes, args.hidden, args.samples
+    rp, ci, _ = O.er_graph(n, args.edges, seed=0)
+    nnz = int(ci.shape[0])
+    P = O.init_params(H, seed=0)
+    x_host = O.make_samples(n, B, H, seed=1000 + rank)            # each rank its own samples
+    grid = ops.time_grid(args.maxTime, args.deltaT)
+    dts = ops.step_sizes(grid)
+    n_steps = int(dts.shape[0])
+
+    g = DeviceGraph(rp, ci)
+    params = {k: torch.from_numpy(v).to(dev) for k, v in P.items()}
+    x = torch.from_numpy(x_host).to(dev)
+    chunk = max(1, min(args.chunk, B))
+    ws = torch.empty(lib.gnode_forward_workspace_bytes(chunk * n, H, 0), dtype=torch.uint8, device=dev)
+
+    def one_pass():
+        outs = []
+        for b0 in range(0, B, chunk):
+            xb = x[b0:b0 + chunk].reshape(-1, 3 + H)
+            outs.append(ops.forward(g, xb, params, dts, "euler", None, False, ws)[:3])
+        return outs
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    sync_all()
+    lib.gnode_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = one_pass()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    import ctypes as C
+    gms, gcnt, mms, mcnt = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
+    lib.gnode_profile_read(C.byref(gms), C.byref(gcnt), C.byref(mms), C.byref(mcnt))
+    lib.gnode_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity on the timed outputs (not timed): probabilities
+    S, I, R = outs[0]
+    tot = (S + I + R)
+    ok = bool(torch.isfinite(tot).all().item()) and abs(float(tot.mean().item()) - 1.0) < 1e-4
+
+    units = world * B * n * n_steps * args.steps
+    value = units / elapsed
+    gather_avg_s = (gms.value / max(gcnt.value, 1)) * 1e-3
+    alg_bytes = algorithmic_bytes_per_sample_step(n, nnz, H) * chunk
+    achieved = alg_bytes / gather_avg_s / 1e9 if gather_avg_s > 0 else 0.0
+
+    result = {
+        "metric": "node-timesteps/sec (N*T/s) GN-ODE fwd, 75k-node graph, hidden=64",
+        "value": value, "unit": "node-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ER G(n={n}, m={args.edges}) nnz={nnz}, H={H}, maxTime={args.maxTime}, deltaT={args.deltaT} "
+                               f"-> {n_steps} Euler steps + read-out at {n_steps + 1} grid points, {B} samples per GPU "
+                               f"(BASELINE configs[3] shape; configs[1..2] are parity cases)",
+                   "samples_per_gpu": B, "samples_per_launch": chunk, "euler_steps": n_steps,
+                   "parallelism": f"sample-sharded x{world}, no data-path collective", "outputs_valid": ok},
+        "node_maxTime_per_s": world * B * n * args.maxTime * args.steps / elapsed,
+        "roofline": {"bound": "hbm", "kernel": "k_gather<16,1> (CSR pull-gather + SIR update + read-out)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "avg_launch_us": gather_avg_s * 1e6, "launches": int(gcnt.value),
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "node_mlp_avg_launch_us": (mms.value / max(mcnt.value, 1)) * 1e3},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        cs = min(args.cpu_steps, n_steps)
+        _, _, _, secs, done = O.torch_port_forward(x_host[:1], P, rp, ci, args.maxTime, args.deltaT, n_steps=cs, threads=cores)
+        result["cpu_baseline"] = {"value": n * done / secs, "unit": "node-timesteps/s", "cores": cores, "kind": "port",
+                                  "sample": f"1 sample x {done} Euler steps of the same graph (reference op sequence "
+                                            f"in PyTorch-CPU: repeat-index + gather + scatter_add_), {secs:.1f} s"}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,616 @@
+// GN-ODE hot path for MI355X (gfx950): node MLP, CSR pull-gather, SIR derivative,
+// Euler/RK4 update and fused read-out.  Hand-written for CDNA4: 64-lane
+// wavefronts, fp32 MFMA for the H=64 node MLP, one sub-wave lane group per node
+// row with 16-byte lane accesses (a 256-B row per 16 lanes at H=64).
+//
+// Reference semantics restated (file:line into the reference tree):
+//   ODEfunc.forward      ode_nn_ngraph_sim.py:58-96   (multi: ode_nn_ngraphs.py:54-83)
+//   ODEBlock.forward     ode_nn_ngraph_sim.py:148-188 (multi: ode_nn_ngraphs.py:124-152)
+//   odeint(euler)        torchdiffeq 0.2.2 fixed grid (call site :168)
+//   get_sir_t_nodes_torch ode_nn.py:249-261 (fused as an output-row list)
+//
+// Compiled with -ffp-contract=off: the elementwise SIR update rounds exactly
+// like the reference's separate torch ops; FMAs are written explicitly where
+// they are wanted (the generic node-MLP inner product).
+#include "gnode_common.h"
+#include <algorithm>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// --------------------------------------------------------------------------- error state
+static thread_local char g_err[512] = "";
+void gnode_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* gnode_last_error(void) { return g_err; }
+extern "C" int gnode_version(void) { return 100; }
+
+// --------------------------------------------------------------------------- instrumentation
+// HIP-event pairs around every launch of the two step kernels while enabled
+// (bench.py's roofline leg: average launch duration measured on the launch stream).
+#include <vector>
+struct ProfKind { std::vector<hipEvent_t> ev; size_t used = 0; };
+static bool g_prof_on = false;
+static ProfKind g_prof[2];   // 0 = gather/update kernel, 1 = node-MLP kernel
+
+static void prof_mark(int kind, hipStream_t st) {
+    if (!g_prof_on) return;
+    ProfKind& k = g_prof[kind];
+    if (k.used == k.ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        k.ev.push_back(e);
+    }
+    (void)hipEventRecord(k.ev[k.used++], st);
+}
+
+extern "C" int gnode_profile_enable(int on) {
+    g_prof_on = on != 0;
+    g_prof[0].used = g_prof[1].used = 0;
+    return 0;
+}
+
+extern "C" int gnode_profile_read(double* gather_ms, int64_t* gather_launches, double* mlp_ms, int64_t* mlp_launches) {
+    double ms[2] = {0.0, 0.0};
+    int64_t cnt[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) {
+        ProfKind& pk = g_prof[k];
+        for (size_t i = 0; i + 1 < pk.used; i += 2) {
+            GN_HIP(hipEventSynchronize(pk.ev[i + 1]));
+            float t = 0.f;
+            GN_HIP(hipEventElapsedTime(&t, pk.ev[i], pk.ev[i + 1]));
+            ms[k] += t;
+            cnt[k] += 1;
+        }
+    }
+    if (gather_ms) *gather_ms = ms[0];
+    if (gather_launches) *gather_launches = cnt[0];
+    if (mlp_ms) *mlp_ms = ms[1];
+    if (mlp_launches) *mlp_launches = cnt[1];
+    return 0;
+}
+
+// --------------------------------------------------------------------------- device helpers
+__device__ __forceinline__ float gn_sigmoid(float x) {
+    // 1 / (1 + exp(-x)) with the hardware exp2/rcp (<= 2 ulp each)
+    return __frcp_rn(1.0f + __expf(-x));
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, LPR);
+    return v;
+}
+
+// Read-out head for one row held by an LPR-lane group (each lane 4 features):
+// Linear(4,1)(relu(Linear(H,4)(y)))  ode_nn_ngraph_sim.py:172-182, for S, I, R, then
+// the 3-way softmax :184-187.  Every lane of the group returns the same values.
+template <int LPR>
+__device__ __forceinline__ void readout_row(float4 yS, float4 yI, float4 yR, bool active, int sub, int H,
+                                            const float* __restrict__ w3, const float* __restrict__ b3,
+                                            const float* __restrict__ w2, const float* __restrict__ b2,
+                                            float& pS, float& pI, float& pR) {
+    float qS = b2[0], qI = b2[0], qR = b2[0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float4 w = active ? ld4(w3 + (size_t)k * H + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float s = fmaf(w.x, yS.x, fmaf(w.y, yS.y, fmaf(w.z, yS.z, w.w * yS.w)));
+        float i = fmaf(w.x, yI.x, fmaf(w.y, yI.y, fmaf(w.z, yI.z, w.w * yI.w)));
+        float r = fmaf(w.x, yR.x, fmaf(w.y, yR.y, fmaf(w.z, yR.z, w.w * yR.w)));
+        s = group_sum<LPR>(s) + b3[k];
+        i = group_sum<LPR>(i) + b3[k];
+        r = group_sum<LPR>(r) + b3[k];
+        qS = fmaf(w2[k], fmaxf(s, 0.f), qS);
+        qI = fmaf(w2[k], fmaxf(i, 0.f), qI);
+        qR = fmaf(w2[k], fmaxf(r, 0.f), qR);
+    }
+    float m = fmaxf(qS, fmaxf(qI, qR));
+    float eS = __expf(qS - m), eI = __expf(qI - m), eR = __expf(qR - m);
+    float inv = 1.0f / (eS + eI + eR);
+    pS = eS * inv; pI = eI * inv; pR = eR * inv;
+}
+
+// --------------------------------------------------------------------------- K0: encoder
+// y0 = cat(relu(Linear(1,H)(S0)), ..(I0), ..(R0), beta_gamma)   ode_nn_ngraph_sim.py:149-168
+// x [rows, 3+H]; Y [3][rows][H]; beta/gamma [rows]; optional sol0 [4*rows, H].
+template <int LPR>
+__global__ __launch_bounds__(256) void k_encode(const float* __restrict__ x, const float* __restrict__ w1,
+                                                const float* __restrict__ b1, float* __restrict__ Y,
+                                                float* __restrict__ beta, float* __restrict__ gamma,
+                                                float* __restrict__ sol0, long rows, int H) {
+    const int sub = threadIdx.x % LPR;
+    const long r = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (r >= rows || 4 * sub >= H) return;
+    const float* xr = x + r * (3 + H);
+    const float s0 = xr[0], i0 = xr[1], r0 = xr[2];
+    const float4 w = ld4(w1 + 4 * sub), b = ld4(b1 + 4 * sub);
+    auto enc = [&](float v) {
+        return make_float4(fmaxf(fmaf(w.x, v, b.x), 0.f), fmaxf(fmaf(w.y, v, b.y), 0.f),
+                           fmaxf(fmaf(w.z, v, b.z), 0.f), fmaxf(fmaf(w.w, v, b.w), 0.f));
+    };
+    const size_t slab = (size_t)rows * H, off = (size_t)r * H + 4 * sub;
+    const float4 yS = enc(s0), yI = enc(i0), yR = enc(r0);
+    st4(Y + off, yS); st4(Y + slab + off, yI); st4(Y + 2 * slab + off, yR);
+    if (sub == 0) { beta[r] = xr[3]; gamma[r] = xr[4]; }
+    if (sol0) {
+        st4(sol0 + off, yS); st4(sol0 + slab + off, yI); st4(sol0 + 2 * slab + off, yR);
+        const float* bg = xr + 3 + 4 * sub;
+        st4(sol0 + 3 * slab + off, make_float4(bg[0], bg[1], bg[2], bg[3]));
+    }
+}
+
+// --------------------------------------------------------------------------- K1: node MLP  Z = sigmoid(Y W^T + b)
+// Generic FMA path (any H % 4 == 0, H <= 128): W^T staged in LDS, one LPR-lane
+// group per row, each lane 4 output features.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_mlp_generic(const float* __restrict__ X, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ Z,
+                                                     long nrows, int H) {
+    extern __shared__ float lds[];
+    float* Wt = lds;                      // [H][H] transposed: Wt[k][j] = W[j][k]
+    float* Xs = lds + (size_t)H * H;      // [256/LPR][H]
+    for (int idx = threadIdx.x; idx < H * H; idx += 256) {
+        int j = idx / H, k = idx % H;
+        Wt[(size_t)k * H + j] = W[idx];
+    }
+    const int sub = threadIdx.x % LPR, g = threadIdx.x / LPR;
+    const long r = (long)blockIdx.x * (256 / LPR) + g;
+    const bool active = (r < nrows) && (4 * sub < H);
+    if (active) st4(Xs + (size_t)g * H + 4 * sub, ld4(X + (size_t)r * H + 4 * sub));
+    __syncthreads();
+    if (!active) return;
+    float4 acc = ld4(bias + 4 * sub);
+    const float* xr = Xs + (size_t)g * H;
+    for (int k = 0; k < H; ++k) {
+        const float xv = xr[k];
+        const float4 w = ld4(Wt + (size_t)k * H + 4 * sub);
+        acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y);
+        acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
+    }
+    st4(Z + (size_t)r * H + 4 * sub,
+        make_float4(gn_sigmoid(acc.x), gn_sigmoid(acc.y), gn_sigmoid(acc.z), gn_sigmoid(acc.w)));
+}
+
+// H = 64 path on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
+// One wave = a 32-row tile; A = X tile (through LDS so the global read is a
+// coalesced 16 B/lane stream), B = W^T fragments held in registers for the whole
+// kernel.  k is visited in the order kappa(q,m,h) = 8q + 4h + m so that each
+// lane's A and B fragments are one 16-byte LDS / global read per q.
+#define MLP_LDS_STRIDE 68  // floats; 272 B rows keep ds_read_b128 conflict-free
+__global__ __launch_bounds__(256) void k_mlp_mfma64(const float* __restrict__ X, const float* __restrict__ W,
+                                                    const float* __restrict__ bias, float* __restrict__ Z,
+                                                    long nrows) {
+    __shared__ float lds[4][32 * MLP_LDS_STRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    float4 wf[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wf[t][q] = ld4(W + (size_t)(32 * t + i) * 64 + 8 * q + 4 * h);
+    const float bias0 = bias[i], bias1 = bias[32 + i];
+    float* tile = lds[wave];
+    const long ntiles = (nrows + 31) / 32;
+    for (long tix = (long)blockIdx.x * 4 + wave; tix < ntiles; tix += (long)gridDim.x * 4) {
+        const long row0 = tix * 32;
+        {   // coalesced stage: 4 rows x 256 B per wave instruction
+            const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const long rr = row0 + 4 * p + g;
+                float4 v = rr < nrows ? ld4(X + (size_t)rr * 64 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                st4(tile + (4 * p + g) * MLP_LDS_STRIDE + 4 * c, v);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = bias0; acc1[r] = bias1; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 a = ld4(tile + i * MLP_LDS_STRIDE + 8 * q + 4 * h);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wf[0][q].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wf[1][q].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wf[0][q].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wf[1][q].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wf[0][q].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wf[1][q].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wf[0][q].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wf[1][q].w, acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // C/D layout: column = lane&31 (feature), row = (r&3) + 8*(r>>2) + 4*h
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (rr < nrows) {
+                Z[(size_t)rr * 64 + i] = gn_sigmoid(acc0[r]);
+                Z[(size_t)rr * 64 + 32 + i] = gn_sigmoid(acc1[r]);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------- K2: gather + SIR derivative (+ Euler update + read-out)
+// AI[r] = sum_{c in adj(node)} Z_I[base + c] in ascending column order (the CPU
+// scatter_add_ order of ode_nn_ngraph_sim.py:73), then :75-77.  One LPR-lane
+// group per row; the group fetches LPR column indices with one coalesced load and
+// broadcasts them by lane shuffle, so neighbour-row loads are issued back to back.
+template <int LPR>
+__device__ __forceinline__ float4 gather_row(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                             const float* __restrict__ ZI_base, int node, int sub, bool active, int H) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int start = rowptr[node], end = rowptr[node + 1];
+    for (int e0 = start; e0 < end; e0 += LPR) {
+        const int cnt = min(LPR, end - e0);
+        const int mine = (sub < cnt) ? col[e0 + sub] : 0;
+        for (int j = 0; j < cnt; j += 4) {
+            const int c0 = __shfl(mine, j, LPR);
+            const int c1 = __shfl(mine, min(j + 1, LPR - 1), LPR);
+            const int c2 = __shfl(mine, min(j + 2, LPR - 1), LPR);
+            const int c3 = __shfl(mine, min(j + 3, LPR - 1), LPR);
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0, v3 = v0;
+            if (active) {
+                v0 = ld4(ZI_base + (size_t)c0 * H + 4 * sub);
+                if (j + 1 < cnt) v1 = ld4(ZI_base + (size_t)c1 * H + 4 * sub);
+                if (j + 2 < cnt) v2 = ld4(ZI_base + (size_t)c2 * H + 4 * sub);
+                if (j + 3 < cnt) v3 = ld4(ZI_base + (size_t)c3 * H + 4 * sub);
+            }
+            acc = add4(acc, v0); acc = add4(acc, v1); acc = add4(acc, v2); acc = add4(acc, v3);
+        }
+    }
+    return acc;
+}
+
+struct StepOut {
+    float* S; float* I; float* R;   // this step's output rows [rows] or null
+    float* sol;                     // sol[g+1] base ([4*rows,H]) or null
+};
+
+// MODE 0: derivative only (dY <- f(Y)), MODE 1: Euler update in place (+ outputs)
+template <int LPR, int MODE>
+__global__ __launch_bounds__(256) void k_gather(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+                                                long rows, int H, float* __restrict__ Y, const float* __restrict__ Z,
+                                                const float* __restrict__ beta, const float* __restrict__ gamma,
+                                                int bg_stride, float dt, float* __restrict__ dY,
+                                                const float* __restrict__ w3, const float* __restrict__ b3,
+                                                const float* __restrict__ w2, const float* __restrict__ b2, StepOut out) {
+    const int sub = threadIdx.x % LPR;
+    const int node = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (node >= n) return;                       // whole lane group leaves together
+    const bool active = 4 * sub < H;
+    const long base = (long)blockIdx.y * n;      // block-diagonal: sample b owns rows [b*n, (b+1)*n)
+    const long r = base + node;
+    const size_t slab = (size_t)rows * H, off = (size_t)r * H + 4 * sub;
+    const float* ZS = Z;
+    const float* ZI = Z + slab;
+
+    const float4 ai = gather_row<LPR>(rowptr, col, ZI + (size_t)base * H, node, sub, active, H);
+    float4 zs = make_float4(0.f, 0.f, 0.f, 0.f), zi = zs;
+    if (active) { zs = ld4(ZS + off); zi = ld4(ZI + off); }
+    const float nb = -beta[(size_t)r * bg_stride], gm = gamma[(size_t)r * bg_stride];
+    float4 dS, dI, dR;
+    dS.x = nb * (ai.x * zs.x); dS.y = nb * (ai.y * zs.y); dS.z = nb * (ai.z * zs.z); dS.w = nb * (ai.w * zs.w);
+    dR.x = gm * zi.x; dR.y = gm * zi.y; dR.z = gm * zi.z; dR.w = gm * zi.w;
+    dI.x = -dS.x - dR.x; dI.y = -dS.y - dR.y; dI.z = -dS.z - dR.z; dI.w = -dS.w - dR.w;
+    if (MODE == 0) {
+        if (active) { st4(dY + off, dS); st4(dY + slab + off, dI); st4(dY + 2 * slab + off, dR); }
+        return;
+    }
+    float4 yS = make_float4(0.f, 0.f, 0.f, 0.f), yI = yS, yR = yS;
+    if (active) {
+        yS = ld4(Y + off); yI = ld4(Y + slab + off); yR = ld4(Y + 2 * slab + off);
+        yS.x += dt * dS.x; yS.y += dt * dS.y; yS.z += dt * dS.z; yS.w += dt * dS.w;
+        yI.x += dt * dI.x; yI.y += dt * dI.y; yI.z += dt * dI.z; yI.w += dt * dI.w;
+        yR.x += dt * dR.x; yR.y += dt * dR.y; yR.z += dt * dR.z; yR.w += dt * dR.w;
+        st4(Y + off, yS); st4(Y + slab + off, yI); st4(Y + 2 * slab + off, yR);
+        if (out.sol) { st4(out.sol + off, yS); st4(out.sol + slab + off, yI); st4(out.sol + 2 * slab + off, yR); }
+    }
+    if (out.S) {
+        float pS, pI, pR;
+        readout_row<LPR>(yS, yI, yR, active, sub, H, w3, b3, w2, b2, pS, pI, pR);
+        if (sub == 0) { out.S[r] = pS; out.I[r] = pI; out.R[r] = pR; }
+    }
+}
+
+// Stand-alone read-out of a state (grid point 0, and every point under RK4).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_readout(const float* __restrict__ Y, long rows, int H,
+                                                 const float* __restrict__ w3, const float* __restrict__ b3,
+                                                 const float* __restrict__ w2, const float* __restrict__ b2,
+                                                 float* __restrict__ S, float* __restrict__ I, float* __restrict__ R) {
+    const int sub = threadIdx.x % LPR;
+    const long r = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (r >= rows) return;
+    const bool active = 4 * sub < H;
+    const size_t slab = (size_t)rows * H, off = (size_t)r * H + 4 * sub;
+    float4 yS = make_float4(0.f, 0.f, 0.f, 0.f), yI = yS, yR = yS;
+    if (active) { yS = ld4(Y + off); yI = ld4(Y + slab + off); yR = ld4(Y + 2 * slab + off); }
+    float pS, pI, pR;
+    readout_row<LPR>(yS, yI, yR, active, sub, H, w3, b3, w2, b2, pS, pI, pR);
+    if (sub == 0) { S[r] = pS; I[r] = pI; R[r] = pR; }
+}
+
+// out = y + a * (c1*k1 + c2*k2 + c3*k3 + c4*k4)   (RK4 3/8-rule stage combinations)
+__global__ __launch_bounds__(256) void k_lincomb(float* __restrict__ out, const float* __restrict__ y, float a,
+                                                 const float* __restrict__ k1, float c1, const float* __restrict__ k2,
+                                                 float c2, const float* __restrict__ k3, float c3,
+                                                 const float* __restrict__ k4, float c4, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = ld4(k1 + 4 * i);
+        float4 s = make_float4(c1 * v.x, c1 * v.y, c1 * v.z, c1 * v.w);
+        if (k2) { v = ld4(k2 + 4 * i); s.x += c2 * v.x; s.y += c2 * v.y; s.z += c2 * v.z; s.w += c2 * v.w; }
+        if (k3) { v = ld4(k3 + 4 * i); s.x += c3 * v.x; s.y += c3 * v.y; s.z += c3 * v.z; s.w += c3 * v.w; }
+        if (k4) { v = ld4(k4 + 4 * i); s.x += c4 * v.x; s.y += c4 * v.y; s.z += c4 * v.z; s.w += c4 * v.w; }
+        v = ld4(y + 4 * i);
+        st4(out + 4 * i, make_float4(v.x + a * s.x, v.y + a * s.y, v.z + a * s.z, v.w + a * s.w));
+    }
+}
+
+// --------------------------------------------------------------------------- host side
+static int lpr_for(int H) {
+    int need = H / 4, l = 1;
+    while (l < need) l <<= 1;
+    return l;
+}
+
+static int check_H(int H) {
+    if (H < 4 || H > 256 || (H % 4) != 0) {
+        gnode_set_error("unsupported hidden size H=%d (need 4 <= H <= 256, H %% 4 == 0)", H);
+        return GNODE_ERR_ARG;
+    }
+    return 0;
+}
+
+#define DISPATCH_LPR(lpr, ...)                                   \
+    switch (lpr) {                                               \
+        case 1: { constexpr int LPR = 1; __VA_ARGS__; } break;   \
+        case 2: { constexpr int LPR = 2; __VA_ARGS__; } break;   \
+        case 4: { constexpr int LPR = 4; __VA_ARGS__; } break;   \
+        case 8: { constexpr int LPR = 8; __VA_ARGS__; } break;   \
+        case 16: { constexpr int LPR = 16; __VA_ARGS__; } break; \
+        case 32: { constexpr int LPR = 32; __VA_ARGS__; } break; \
+        default: { constexpr int LPR = 64; __VA_ARGS__; } break; \
+    }
+
+static int launch_mlp(const float* X, const float* W, const float* b, float* Z, long nrows, int H, hipStream_t st) {
+    if (nrows == 0) return 0;
+    prof_mark(1, st);
+    if (H == 64) {
+        long ntiles = (nrows + 31) / 32;
+        int grid = (int)std::min<long>((ntiles + 3) / 4, 256L * 8);
+        hipLaunchKernelGGL(k_mlp_mfma64, dim3(grid), dim3(256), 0, st, X, W, b, Z, nrows);
+    } else {
+        GN_CHECK_ARG(H <= 128, "generic node-MLP path supports H <= 128 (got %d)", H);
+        const int lpr = lpr_for(H);
+        const int rpw = 256 / lpr;
+        const size_t lds = ((size_t)H * H + (size_t)rpw * H) * sizeof(float);
+        DISPATCH_LPR(lpr, {
+            if (lds > 64 * 1024)
+                GN_HIP(hipFuncSetAttribute((const void*)k_mlp_generic<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_mlp_generic<LPR>, dim3((unsigned)((nrows + rpw - 1) / rpw)), dim3(256), lds, st, X, W, b, Z, nrows, H);
+        });
+    }
+    prof_mark(1, st);
+    GN_LAUNCH_CHECK();
+    return 0;
+}
+
+// dY or in-place Euler update from (Y, Z)
+static int launch_gather(gnode_graph_t g, int mode, long rows, int H, float* Y, const float* Z, const float* beta,
+                         const float* gamma, int bg_stride, float dt, float* dY, const gnode_params* p, StepOut out,
+                         hipStream_t st) {
+    const int lpr = lpr_for(H), rpw = 256 / lpr;
+    const long B = rows / g->n;
+    dim3 grid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)B);
+    const float *w3 = p ? p->linear3_weight : nullptr, *b3 = p ? p->linear3_bias : nullptr;
+    const float *w2 = p ? p->linearS2_weight : nullptr, *b2 = p ? p->linearS2_bias : nullptr;
+    prof_mark(0, st);
+    if (mode == 0) {
+        DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_gather<LPR, 0>), grid, dim3(256), 0, st, g->rowptr, g->col, g->n, rows, H,
+                                             Y, Z, beta, gamma, bg_stride, dt, dY, w3, b3, w2, b2, out));
+    } else {
+        DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_gather<LPR, 1>), grid, dim3(256), 0, st, g->rowptr, g->col, g->n, rows, H,
+                                             Y, Z, beta, gamma, bg_stride, dt, dY, w3, b3, w2, b2, out));
+    }
+    prof_mark(0, st);
+    GN_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_readout(const float* Y, long rows, int H, const gnode_params* p, float* S, float* I, float* R,
+                          hipStream_t st) {
+    const int lpr = lpr_for(H), rpw = 256 / lpr;
+    DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_readout<LPR>, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), 0, st, Y,
+                                         rows, H, p->linear3_weight, p->linear3_bias, p->linearS2_weight,
+                                         p->linearS2_bias, S, I, R));
+    GN_LAUNCH_CHECK();
+    return 0;
+}
+
+// --------------------------------------------------------------------------- graph handle
+extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col_host, int32_t n, int64_t nnz,
+                                  gnode_graph_t* out) {
+    GN_CHECK_ARG(rowptr_host && out && n > 0 && nnz >= 0, "gnode_graph_create: null pointer or empty graph");
+    GN_CHECK_ARG(col_host || nnz == 0, "gnode_graph_create: col is null");
+    GN_CHECK_ARG(rowptr_host[0] == 0 && rowptr_host[n] == nnz, "gnode_graph_create: rowptr[0] != 0 or rowptr[n] != nnz");
+    int32_t maxdeg = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const int32_t d = rowptr_host[i + 1] - rowptr_host[i];
+        GN_CHECK_ARG(d >= 0, "gnode_graph_create: rowptr not monotone at %d", i);
+        maxdeg = d > maxdeg ? d : maxdeg;
+    }
+    for (int64_t e = 0; e < nnz; ++e)
+        GN_CHECK_ARG(col_host[e] >= 0 && col_host[e] < n, "gnode_graph_create: col[%lld]=%d out of range",
+                     (long long)e, col_host[e]);
+    gnode_graph_s* g = new gnode_graph_s();
+    g->n = n; g->nnz = nnz; g->max_degree = maxdeg; g->rowptr = nullptr; g->col = nullptr;
+    hipError_t e1 = hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n + 1));
+    hipError_t e2 = hipMalloc(&g->col, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        gnode_set_error("gnode_graph_create: hipMalloc failed");
+        if (g->rowptr) (void)hipFree(g->rowptr);
+        if (g->col) (void)hipFree(g->col);
+        delete g;
+        return GNODE_ERR_HIP;
+    }
+    GN_HIP(hipMemcpy(g->rowptr, rowptr_host, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+    if (nnz) GN_HIP(hipMemcpy(g->col, col_host, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    *out = g;
+    return 0;
+}
+
+extern "C" int gnode_graph_destroy(gnode_graph_t g) {
+    if (!g) return 0;
+    (void)hipFree(g->rowptr);
+    (void)hipFree(g->col);
+    delete g;
+    return 0;
+}
+
+extern "C" int gnode_graph_info(gnode_graph_t g, int32_t* n, int64_t* nnz, int32_t* max_degree) {
+    GN_CHECK_ARG(g, "gnode_graph_info: null graph");
+    if (n) *n = g->n;
+    if (nnz) *nnz = g->nnz;
+    if (max_degree) *max_degree = g->max_degree;
+    return 0;
+}
+
+// --------------------------------------------------------------------------- RHS
+extern "C" size_t gnode_rhs_workspace_bytes(int64_t rows, int32_t H) {
+    return gn_align((size_t)2 * rows * H * sizeof(float));
+}
+
+extern "C" int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* b, float* dx, int64_t rows,
+                             int32_t H, void* workspace, size_t workspace_bytes, void* stream) {
+    GN_CHECK_ARG(g && x && W && b && dx && workspace, "gnode_rhs_f32: null pointer");
+    if (int e = check_H(H)) return e;
+    GN_CHECK_ARG(H >= 2, "gnode_rhs_f32: H >= 2 required (beta, gamma live in columns 0, 1)");
+    GN_CHECK_ARG(rows > 0 && rows % g->n == 0, "gnode_rhs_f32: rows=%lld is not a multiple of graph n=%d",
+                 (long long)rows, g->n);
+    if (workspace_bytes < gnode_rhs_workspace_bytes(rows, H)) {
+        gnode_set_error("gnode_rhs_f32: workspace %zu < %zu", workspace_bytes, gnode_rhs_workspace_bytes(rows, H));
+        return GNODE_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* Z = (float*)workspace;
+    const size_t slab = (size_t)rows * H;
+    if (int e = launch_mlp(x, W, b, Z, 2 * rows, H, st)) return e;      // R' is dead work in the reference: skipped
+    StepOut none = {nullptr, nullptr, nullptr, nullptr};
+    if (int e = launch_gather(g, 0, rows, H, const_cast<float*>(x), Z, x + 3 * slab, x + 3 * slab + 1, H, 0.f, dx,
+                              nullptr, none, st))
+        return e;
+    GN_HIP(hipMemsetAsync(dx + 3 * slab, 0, slab * sizeof(float), st));  // 4th slab derivative = 0 (:96)
+    return 0;
+}
+
+// --------------------------------------------------------------------------- forward
+extern "C" size_t gnode_forward_workspace_bytes(int64_t rows, int32_t H, int32_t method) {
+    const size_t slab = gn_align((size_t)rows * H * sizeof(float));
+    size_t nslab = 5;                       // Y[3], Z[2]
+    if (method == 1) nslab += 3 * 5;        // k1..k4, ytmp (3 slabs each)
+    return nslab * slab + 2 * gn_align((size_t)rows * sizeof(float));
+}
+
+extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
+                                 int32_t n_steps, int32_t method, const int32_t* out_rows_host, int32_t n_out, float* S,
+                                 float* I, float* R, float* sol, int64_t rows, int32_t H, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    GN_CHECK_ARG(g && x && p && S && I && R && workspace, "gnode_forward_f32: null pointer");
+    GN_CHECK_ARG(n_steps >= 0 && (n_steps == 0 || dt_host), "gnode_forward_f32: bad n_steps/dt");
+    GN_CHECK_ARG(method == 0 || method == 1, "gnode_forward_f32: method must be 0 (euler) or 1 (rk4)");
+    if (int e = check_H(H)) return e;
+    GN_CHECK_ARG(H >= 2, "gnode_forward_f32: H >= 2 required (beta, gamma live in columns 3, 4 of x)");
+    GN_CHECK_ARG(rows > 0 && rows % g->n == 0, "gnode_forward_f32: rows=%lld is not a multiple of graph n=%d",
+                 (long long)rows, g->n);
+    GN_CHECK_ARG(p->odefunc_linear_weight && p->odefunc_linear_bias && p->linearS1_weight && p->linearS1_bias &&
+                     p->linear3_weight && p->linear3_bias && p->linearS2_weight && p->linearS2_bias,
+                 "gnode_forward_f32: null parameter pointer");
+    if (workspace_bytes < gnode_forward_workspace_bytes(rows, H, method)) {
+        gnode_set_error("gnode_forward_f32: workspace %zu < %zu", workspace_bytes,
+                        gnode_forward_workspace_bytes(rows, H, method));
+        return GNODE_ERR_WORKSPACE;
+    }
+    const int G = n_steps + 1;
+    if (out_rows_host) {
+        GN_CHECK_ARG(n_out >= 0, "gnode_forward_f32: n_out < 0");
+        for (int i = 0; i < n_out; ++i)
+            GN_CHECK_ARG(out_rows_host[i] >= 0 && out_rows_host[i] < G && (i == 0 || out_rows_host[i] > out_rows_host[i - 1]),
+                         "gnode_forward_f32: out_rows must be ascending grid indices in [0,%d)", G);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t slab = (size_t)rows * H, slab_b = gn_align(slab * sizeof(float));
+    char* ws = (char*)workspace;
+    float* Y = (float*)ws;                       // [3][rows][H] (contiguous: slab strides are elements, not aligned bytes)
+    // keep slabs element-contiguous: Y uses 3*slab floats inside 3 aligned slabs
+    float* Z = (float*)(ws + 3 * slab_b);
+    float* beta = (float*)(ws + 5 * slab_b);
+    float* gamma = (float*)(ws + 5 * slab_b + gn_align((size_t)rows * sizeof(float)));
+    float* rk = (float*)(ws + 5 * slab_b + 2 * gn_align((size_t)rows * sizeof(float)));
+
+    const int lpr = lpr_for(H), rpw = 256 / lpr;
+    DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_encode<LPR>, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), 0, st, x,
+                                         p->linearS1_weight, p->linearS1_bias, Y, beta, gamma, sol, (long)rows, H));
+    GN_LAUNCH_CHECK();
+
+    int next_out = 0;  // index into the output list
+    auto out_slot = [&](int gidx) -> int {   // which output row (or -1) grid point gidx is written to
+        if (!out_rows_host) return gidx;
+        if (next_out < n_out && out_rows_host[next_out] == gidx) return next_out++;
+        return -1;
+    };
+    int slot = out_slot(0);
+    if (slot >= 0)
+        if (int e = launch_readout(Y, rows, H, p, S + (size_t)slot * rows, I + (size_t)slot * rows, R + (size_t)slot * rows, st))
+            return e;
+
+    for (int k = 0; k < n_steps; ++k) {
+        const float dt = dt_host[k];
+        slot = out_slot(k + 1);
+        float* sol_next = sol ? sol + (size_t)(k + 1) * 4 * slab : nullptr;
+        if (method == 0) {
+            if (int e = launch_mlp(Y, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
+            StepOut out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
+                           slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
+            if (int e = launch_gather(g, 1, rows, H, Y, Z, beta, gamma, 1, dt, nullptr, p, out, st)) return e;
+        } else {
+            // torchdiffeq 'rk4' = 3/8 rule
+            float* k1 = rk; float* k2 = rk + 3 * slab; float* k3 = rk + 6 * slab; float* k4 = rk + 9 * slab;
+            float* yt = rk + 12 * slab;
+            const size_t n4 = 3 * slab / 4;
+            const int eg = (int)std::min<size_t>((n4 + 255) / 256, 2048);
+            StepOut none = {nullptr, nullptr, nullptr, nullptr};
+            auto f = [&](float* y, float* kout) -> int {
+                if (int e = launch_mlp(y, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
+                return launch_gather(g, 0, rows, H, y, Z, beta, gamma, 1, 0.f, kout, nullptr, none, st);
+            };
+            const float third = 1.0f / 3.0f;
+            if (int e = f(Y, k1)) return e;
+            hipLaunchKernelGGL(k_lincomb, dim3(eg), dim3(256), 0, st, yt, Y, dt, k1, third, nullptr, 0.f, nullptr, 0.f, nullptr, 0.f, n4);
+            if (int e = f(yt, k2)) return e;
+            hipLaunchKernelGGL(k_lincomb, dim3(eg), dim3(256), 0, st, yt, Y, dt, k1, -third, k2, 1.f, nullptr, 0.f, nullptr, 0.f, n4);
+            if (int e = f(yt, k3)) return e;
+            hipLaunchKernelGGL(k_lincomb, dim3(eg), dim3(256), 0, st, yt, Y, dt, k1, 1.f, k2, -1.f, k3, 1.f, nullptr, 0.f, n4);
+            if (int e = f(yt, k4)) return e;
+            hipLaunchKernelGGL(k_lincomb, dim3(eg), dim3(256), 0, st, Y, Y, dt, k1, 0.125f, k2, 0.375f, k3, 0.375f, k4, 0.125f, n4);
+            GN_LAUNCH_CHECK();
+            if (sol_next) GN_HIP(hipMemcpyAsync(sol_next, Y, 3 * slab * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if (slot >= 0)
+                if (int e = launch_readout(Y, rows, H, p, S + (size_t)slot * rows, I + (size_t)slot * rows,
+                                           R + (size_t)slot * rows, st))
+                    return e;
+        }
+        if (sol_next)  // 4th slab rides along unchanged (derivative 0, ode_nn_ngraph_sim.py:96)
+            GN_HIP(hipMemcpyAsync(sol_next + 3 * slab, sol + 3 * slab, slab * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+}

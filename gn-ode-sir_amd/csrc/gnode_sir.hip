@@ -1,0 +1,293 @@
+// Monte-Carlo SIR label generator for MI355X (gfx950).
+//
+// Restates sir_torch (reference ode_nn.py:30-88): `sims` independent discrete-time
+// SIR trajectories; per step every (infected u -> susceptible v) directed edge
+// fires with probability beta and every infected node recovers with probability
+// gamma, both decided on the pre-step state (:60-78); per-(t, node) membership
+// counts are accumulated (:80-82) with row 0 ASSIGNED (:55-56).
+//
+// The reference runs ~20 torch launches and >= 4 host syncs per (sim, step).
+// Here one workgroup owns one trajectory with its node state in LDS (1 byte per
+// node), scans the directed edge list cooperatively, and records only the two
+// EVENTS a node can have (infection step, recovery step) with integer atomics;
+// a final pass turns the event histograms into the S/I/R counts by a prefix sum
+// over time.  All arithmetic is integer: results are bit-exact and independent
+// of scheduling.
+#include "gnode_common.h"
+#include <algorithm>
+
+enum : uint8_t { ST_S = 0, ST_I = 1, ST_R = 2 };
+
+// --------------------------------------------------------------------------- Philox4x32-10
+__device__ __forceinline__ uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                 uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+// --------------------------------------------------------------------------- production kernel
+// hist: uint32 [2][T][n]: [0] = infection events (t = 0 for seeds), [1] = recovery events.
+template <bool STATE_IN_LDS>
+__global__ __launch_bounds__(256) void k_sir_philox(const int* __restrict__ src, const int* __restrict__ dst, long nnz,
+                                                    int n, const int* __restrict__ seeds, int n_seeds,
+                                                    unsigned long long thr_beta, unsigned long long thr_gamma,
+                                                    long sims, long sim_offset, int T, uint32_t k0, uint32_t k1,
+                                                    uint32_t* __restrict__ hist, uint8_t* __restrict__ gstate) {
+    extern __shared__ uint8_t smem[];
+    uint8_t* state = STATE_IN_LDS ? smem : gstate + (size_t)blockIdx.x * 2 * n;
+    uint8_t* flag = state + n;
+    uint32_t* hinf = hist;
+    uint32_t* hrec = hist + (size_t)T * n;
+    for (long s = blockIdx.x; s < sims; s += gridDim.x) {
+        const uint32_t sim = (uint32_t)(sim_offset + s);
+        for (int v = threadIdx.x; v < n; v += 256) { state[v] = ST_S; flag[v] = 0; }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n_seeds; j += 256) state[seeds[j]] = ST_I;   // duplicates: same value
+        __syncthreads();
+        for (int j = threadIdx.x; j < n_seeds; j += 256) {
+            // one infection event at t=0 per distinct seed node
+            const int v = seeds[j];
+            bool first = true;
+            for (int q = 0; q < j; ++q) first = first && (seeds[q] != v);
+            if (first) atomicAdd(&hinf[v], 1u);
+        }
+        for (int it = 1; it < T; ++it) {
+            for (long e = threadIdx.x; e < nnz; e += 256) {
+                const int u = src[e];
+                if (state[u] == ST_I) {
+                    const int v = dst[e];
+                    if (state[v] == ST_S &&
+                        (unsigned long long)philox_word0((uint32_t)e, (uint32_t)it, sim, 0u, k0, k1) < thr_beta)
+                        flag[v] = 1;
+                }
+            }
+            for (int u = threadIdx.x; u < n; u += 256)
+                if (state[u] == ST_I &&
+                    (unsigned long long)philox_word0((uint32_t)u, (uint32_t)it, sim, 1u, k0, k1) < thr_gamma)
+                    flag[u] = 2;
+            __syncthreads();
+            int any = 0;
+            for (int v = threadIdx.x; v < n; v += 256) {
+                const uint8_t f = flag[v];
+                if (f == 1) { state[v] = ST_I; atomicAdd(&hinf[(size_t)it * n + v], 1u); }
+                else if (f == 2) { state[v] = ST_R; atomicAdd(&hrec[(size_t)it * n + v], 1u); }
+                flag[v] = 0;
+                any |= (state[v] == ST_I);
+            }
+            if (!__syncthreads_or(any)) break;      // epidemic over: no further events in this trajectory
+        }
+        __syncthreads();
+    }
+}
+
+// counts[0..2][t][v] += (sims - cumInf, cumInf - cumRec, cumRec) for t >= 1; row 0 assigned.
+__global__ __launch_bounds__(256) void k_sir_finalize(const uint32_t* __restrict__ hist, int n, int T, uint32_t sims,
+                                                      uint32_t* __restrict__ counts) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const uint32_t* hinf = hist;
+    const uint32_t* hrec = hist + (size_t)T * n;
+    const size_t plane = (size_t)T * n;
+    uint32_t ci = hinf[v], cr = 0;
+    const uint32_t seeded = ci ? 1u : 0u;            // every trajectory starts from the same seed set
+    counts[v] = 1u - seeded;                         // S row 0: assigned, ode_nn.py:56
+    counts[plane + v] = seeded;                      // I row 0: assigned, ode_nn.py:55
+    ci = seeded * sims;
+    for (int t = 1; t < T; ++t) {
+        ci += hinf[(size_t)t * n + v];
+        cr += hrec[(size_t)t * n + v];
+        counts[(size_t)t * n + v] += sims - ci;
+        counts[plane + (size_t)t * n + v] += ci - cr;
+        counts[2 * plane + (size_t)t * n + v] += cr;
+    }
+}
+
+// src[e] for every CSR position (row expansion), once per call
+__global__ void k_expand_rows(const int* __restrict__ rowptr, int n, int* __restrict__ src) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    for (int e = rowptr[u]; e < rowptr[u + 1]; ++e) src[e] = u;
+}
+
+// --------------------------------------------------------------------------- parity kernel (recorded coin stream)
+__device__ __forceinline__ int block_rank(bool pred, int* wave_tot, int& total) {
+    // stable exclusive rank of `pred` lanes over the 256-thread block
+    const unsigned long long m = __ballot(pred);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) wave_tot[w] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int c = wave_tot[q]; base += (q < w) ? c : 0; total += c; }
+    return base + r;
+}
+
+__global__ __launch_bounds__(256) void k_sir_coins(const int* __restrict__ tsrc, const int* __restrict__ tdst, long nt,
+                                                   int n, const int* __restrict__ seeds, int n_seeds, double beta,
+                                                   double gamma, long sims, int T, const double* __restrict__ coins,
+                                                   long n_coins, uint32_t* __restrict__ counts,
+                                                   long long* __restrict__ used) {
+    extern __shared__ uint8_t smem[];
+    uint8_t* state = smem;
+    uint8_t* flag = smem + n;
+    __shared__ int wave_tot[4];
+    const size_t plane = (size_t)T * n;
+    long pos = 0;
+    bool overrun = false;
+    for (long s = 0; s < sims; ++s) {
+        for (int v = threadIdx.x; v < n; v += 256) { state[v] = ST_S; flag[v] = 0; }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n_seeds; j += 256) state[seeds[j]] = ST_I;
+        __syncthreads();
+        for (int v = threadIdx.x; v < n; v += 256) {          // row 0 assigned each sim (ode_nn.py:55-56)
+            counts[v] = state[v] == ST_S;
+            counts[plane + v] = state[v] == ST_I;
+        }
+        for (int it = 1; it < T; ++it) {
+            // coins #1: one per active table row, in table order (ode_nn.py:61-67)
+            for (long e0 = 0; e0 < nt; e0 += 256) {
+                const long e = e0 + threadIdx.x;
+                int v = 0;
+                bool act = false;
+                if (e < nt) { v = tdst[e]; act = state[tsrc[e]] == ST_I && state[v] == ST_S; }
+                int total;
+                const int rk = block_rank(act, wave_tot, total);
+                if (act) {
+                    const long ci = pos + rk;
+                    if (ci < n_coins) { if (coins[ci] < beta) flag[v] = 1; } else overrun = true;
+                }
+                pos += total;
+            }
+            __syncthreads();
+            // coins #2: one per infected node, ascending id (ode_nn.py:70-72)
+            for (int u0 = 0; u0 < n; u0 += 256) {
+                const int u = u0 + threadIdx.x;
+                const bool inf = u < n && state[u] == ST_I;
+                int total;
+                const int rk = block_rank(inf, wave_tot, total);
+                if (inf) {
+                    const long ci = pos + rk;
+                    if (ci < n_coins) { if (coins[ci] < gamma) flag[u] = 2; } else overrun = true;
+                }
+                pos += total;
+            }
+            __syncthreads();
+            for (int v = threadIdx.x; v < n; v += 256) {
+                const uint8_t f = flag[v];
+                if (f == 1) state[v] = ST_I; else if (f == 2) state[v] = ST_R;
+                flag[v] = 0;
+                const uint8_t st = state[v];
+                counts[(size_t)it * n + v] += st == ST_S;
+                counts[plane + (size_t)it * n + v] += st == ST_I;
+                counts[2 * plane + (size_t)it * n + v] += st == ST_R;
+            }
+            __syncthreads();
+        }
+    }
+    if (__syncthreads_or(overrun)) pos = -1;
+    if (threadIdx.x == 0) *used = pos;
+}
+
+// --------------------------------------------------------------------------- host side
+static const size_t kLdsStateLimit = 150 * 1024;   // of the CU's 160 KiB
+
+extern "C" size_t gnode_sir_coins_workspace_bytes(void) { return gn_align(4096 * sizeof(int32_t)) + gn_align(64); }
+
+extern "C" size_t gnode_sir_workspace_bytes(gnode_graph_t g, int32_t T) {
+    if (!g) return 0;
+    size_t b = gn_align((size_t)2 * T * g->n * sizeof(uint32_t)) + gn_align(4096 * sizeof(int32_t)) +
+               gn_align((size_t)std::max<int64_t>(g->nnz, 1) * sizeof(int32_t));
+    if ((size_t)2 * g->n > kLdsStateLimit) b += gn_align((size_t)2048 * 2 * g->n);
+    return b;
+}
+
+extern "C" int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta,
+                                   double gamma, int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed,
+                                   uint32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
+    GN_CHECK_ARG(g && counts && workspace, "gnode_sir_mc_philox: null pointer");
+    GN_CHECK_ARG(n_seeds >= 0 && n_seeds <= 4096 && (seeds_host || n_seeds == 0), "gnode_sir_mc_philox: 0..4096 seeds");
+    GN_CHECK_ARG(T >= 1 && sims >= 0 && sims <= 0xFFFFFFFFll && sim_offset >= 0 && sim_offset + sims <= 0xFFFFFFFFll,
+                 "gnode_sir_mc_philox: bad T/sims/sim_offset");
+    GN_CHECK_ARG(beta >= 0.0 && beta <= 1.0 && gamma >= 0.0 && gamma <= 1.0, "gnode_sir_mc_philox: beta, gamma in [0,1]");
+    for (int i = 0; i < n_seeds; ++i)
+        GN_CHECK_ARG(seeds_host[i] >= 0 && seeds_host[i] < g->n, "gnode_sir_mc_philox: seed %d out of range", seeds_host[i]);
+    if (workspace_bytes < gnode_sir_workspace_bytes(g, T)) {
+        gnode_set_error("gnode_sir_mc_philox: workspace %zu < %zu", workspace_bytes, gnode_sir_workspace_bytes(g, T));
+        return GNODE_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const size_t hist_b = gn_align((size_t)2 * T * g->n * sizeof(uint32_t));
+    uint32_t* hist = (uint32_t*)ws;
+    int32_t* seeds = (int32_t*)(ws + hist_b);
+    int32_t* src = (int32_t*)(ws + hist_b + gn_align(4096 * sizeof(int32_t)));
+    uint8_t* gstate = (uint8_t*)(ws + hist_b + gn_align(4096 * sizeof(int32_t)) +
+                                 gn_align((size_t)std::max<int64_t>(g->nnz, 1) * sizeof(int32_t)));
+    GN_HIP(hipMemsetAsync(hist, 0, hist_b, st));
+    if (n_seeds) GN_HIP(hipMemcpyAsync(seeds, seeds_host, sizeof(int32_t) * n_seeds, hipMemcpyHostToDevice, st));
+    GN_HIP(hipStreamSynchronize(st));    // seeds_host may be a temporary of the caller
+    hipLaunchKernelGGL(k_expand_rows, dim3((g->n + 255) / 256), dim3(256), 0, st, g->rowptr, g->n, src);
+    GN_LAUNCH_CHECK();
+    const unsigned long long tb = (unsigned long long)std::min(4294967296.0, std::max(0.0, std::floor(beta * 4294967296.0)));
+    const unsigned long long tg = (unsigned long long)std::min(4294967296.0, std::max(0.0, std::floor(gamma * 4294967296.0)));
+    const uint32_t k0 = (uint32_t)(rng_seed & 0xFFFFFFFFull), k1 = (uint32_t)(rng_seed >> 32);
+    if (sims > 0) {
+        const size_t lds = (size_t)2 * g->n;
+        if (lds <= kLdsStateLimit) {
+            if (lds > 64 * 1024)
+                GN_HIP(hipFuncSetAttribute((const void*)k_sir_philox<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int grid = (int)std::min<int64_t>(sims, 256 * 8);
+            hipLaunchKernelGGL(k_sir_philox<true>, dim3(grid), dim3(256), lds, st, src, g->col, (long)g->nnz, g->n, seeds,
+                               n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (uint8_t*)nullptr);
+        } else {
+            const int grid = (int)std::min<int64_t>(sims, 2048);
+            hipLaunchKernelGGL(k_sir_philox<false>, dim3(grid), dim3(256), 0, st, src, g->col, (long)g->nnz, g->n, seeds,
+                               n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, gstate);
+        }
+        GN_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_sir_finalize, dim3((g->n + 255) / 256), dim3(256), 0, st, hist, g->n, T, (uint32_t)sims, counts);
+    GN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gnode_sir_mc_coins(const int32_t* table_src, const int32_t* table_dst, int64_t n_table, int32_t n,
+                                  const int32_t* seeds_host, int32_t n_seeds, double beta, double gamma, int64_t sims,
+                                  int32_t T, const double* coins, int64_t n_coins, uint32_t* counts,
+                                  int64_t* coins_used_host, void* workspace, size_t workspace_bytes, void* stream) {
+    GN_CHECK_ARG(table_src && table_dst && counts && workspace && coins_used_host && (coins || n_coins == 0),
+                 "gnode_sir_mc_coins: null pointer");
+    GN_CHECK_ARG(n > 0 && (size_t)2 * n <= 64 * 1024, "gnode_sir_mc_coins: parity mode supports n <= 32768 (got %d)", n);
+    GN_CHECK_ARG(n_seeds >= 0 && n_seeds <= 4096 && T >= 1 && sims >= 0 && n_table >= 0, "gnode_sir_mc_coins: bad sizes");
+    for (int i = 0; i < n_seeds; ++i)
+        GN_CHECK_ARG(seeds_host[i] >= 0 && seeds_host[i] < n, "gnode_sir_mc_coins: seed %d out of range", seeds_host[i]);
+    if (workspace_bytes < gnode_sir_coins_workspace_bytes()) {
+        gnode_set_error("gnode_sir_mc_coins: workspace too small");
+        return GNODE_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* seeds = (int32_t*)workspace;
+    long long* used = (long long*)((char*)workspace + gn_align(4096 * sizeof(int32_t)));
+    if (n_seeds) GN_HIP(hipMemcpyAsync(seeds, seeds_host, sizeof(int32_t) * n_seeds, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_sir_coins, dim3(1), dim3(256), (size_t)2 * n, st, table_src, table_dst, (long)n_table, n, seeds,
+                       n_seeds, beta, gamma, (long)sims, T, coins, (long)n_coins, counts, used);
+    GN_LAUNCH_CHECK();
+    long long h = 0;
+    GN_HIP(hipMemcpyAsync(&h, used, sizeof(h), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipStreamSynchronize(st));
+    *coins_used_host = h;
+    if (h < 0) {
+        gnode_set_error("gnode_sir_mc_coins: coin stream exhausted (n_coins=%lld)", (long long)n_coins);
+        return GNODE_ERR_ARG;
+    }
+    return 0;
+}

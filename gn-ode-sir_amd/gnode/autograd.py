@@ -1,0 +1,45 @@
+"""Autograd bridge for ODEBlock.forward.
+
+Inference (no_grad, or nothing requires grad) calls the fused forward and never
+materialises the trajectory.  Training saves `sol` as torchdiffeq's
+odeint_adjoint does and runs the adjoint-Euler backward in
+libgnode_hip.so.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def _needs_grad(params: dict) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for p in params.values())
+
+
+class _GNODEForward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, x2d, dts, method, out_rows, keys, *tensors):
+        params = dict(zip(keys, tensors))
+        S, I, R, sol = ops.forward(graph, x2d, params, dts, method, out_rows, want_sol=True)
+        ctx.graph, ctx.dts, ctx.method, ctx.out_rows, ctx.keys = graph, dts, method, out_rows, keys
+        ctx.save_for_backward(x2d, sol, *tensors)
+        return S, I, R
+
+    @staticmethod
+    def backward(ctx, gS, gI, gR):
+        x2d, sol, *tensors = ctx.saved_tensors
+        params = dict(zip(ctx.keys, tensors))
+        if not hasattr(ops, "backward"):
+            raise NotImplementedError("GN-ODE adjoint backward is not built in this revision")
+        grads = ops.backward(ctx.graph, x2d, params, ctx.dts, ctx.method, ctx.out_rows, sol,
+                             gS.contiguous(), gI.contiguous(), gR.contiguous())
+        return (None, None, None, None, None, None, *[grads[k] for k in ctx.keys])
+
+
+def forward_with_grad(graph, x2d, params, dts, method="euler", out_rows=None):
+    if not _needs_grad(params):
+        with torch.no_grad():
+            S, I, R, _ = ops.forward(graph, x2d, {k: v.detach() for k, v in params.items()}, dts, method, out_rows)
+        return S, I, R
+    keys = tuple(params.keys())
+    return _GNODEForward.apply(graph, x2d, dts, method, out_rows, keys, *[params[k] for k in keys])

@@ -1,0 +1,122 @@
+"""Drop-in for the helpers of reference ode_nn.py that sit on the hot path:
+
+    sir_torch(G, seed_set, beta, gamma, sims=10000, T=20)        reference :30-88
+    get_sir_t_nodes_torch(x_rk, maxTime, deltaT, count=True)     reference :249-261
+    create_graph(n_nodes, graph_label='none')                    reference :394-414
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pickle
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+from .graph import DeviceGraph
+
+
+def _edge_arrays(G):
+    e = np.asarray(list(G.edges()), dtype=np.int64).reshape(-1, 2)
+    return e
+
+
+def _csr_from_edges(n, e):
+    r = np.concatenate([e[:, 0], e[:, 1]])
+    c = np.concatenate([e[:, 1], e[:, 0]])
+    a = sp.coo_matrix((np.ones(r.shape[0], dtype=np.int8), (r, c)), shape=(n, n)).tocsr()
+    a.sum_duplicates()
+    a.sort_indices()
+    return a.indptr.astype(np.int32), a.indices.astype(np.int32)
+
+
+def sir_counts(graph: DeviceGraph, seed_set, beta, gamma, sims, T, rng_seed, sim_offset=0, device="cuda",
+               counts: torch.Tensor | None = None) -> torch.Tensor:
+    """Production Monte-Carlo on the GPU: uint32 (stored as int32 tensor) counts [3, T, n].
+
+    `counts` may be passed to accumulate several shards of the sims range into one array."""
+    lib = _lib.load()
+    seeds = np.ascontiguousarray(list(seed_set), dtype=np.int32)
+    if counts is None:
+        counts = torch.zeros((3, T, graph.n), dtype=torch.int32, device=device)
+    ws_bytes = lib.gnode_sir_workspace_bytes(graph.handle, T)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=counts.device)
+    _lib.check(lib.gnode_sir_mc_philox(graph.handle, _lib.host_ptr(seeds), int(seeds.shape[0]), float(beta), float(gamma),
+                                       int(sims), int(sim_offset), int(T), C.c_uint64(int(rng_seed) & (2**64 - 1)),
+                                       _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    return counts
+
+
+def sir_counts_coins(n, table: np.ndarray, seed_set, beta, gamma, sims, T, coins: np.ndarray, device="cuda"):
+    """Parity mode: consume a recorded torch.rand stream exactly like the reference.
+    Returns (counts int32 [3,T,n] on the GPU, coins consumed)."""
+    lib = _lib.load()
+    seeds = np.ascontiguousarray(list(seed_set), dtype=np.int32)
+    tsrc = torch.from_numpy(np.ascontiguousarray(table[:, 0], dtype=np.int32)).to(device)
+    tdst = torch.from_numpy(np.ascontiguousarray(table[:, 1], dtype=np.int32)).to(device)
+    cz = torch.from_numpy(np.ascontiguousarray(coins, dtype=np.float64)).to(device)
+    counts = torch.zeros((3, T, n), dtype=torch.int32, device=device)
+    ws = torch.empty(lib.gnode_sir_coins_workspace_bytes(), dtype=torch.uint8, device=device)
+    used = C.c_int64(0)
+    _lib.check(lib.gnode_sir_mc_coins(_lib.ptr(tsrc), _lib.ptr(tdst), int(tsrc.numel()), int(n), _lib.host_ptr(seeds),
+                                      int(seeds.shape[0]), float(beta), float(gamma), int(sims), int(T),
+                                      _lib.ptr(cz) if cz.numel() else None, int(cz.numel()), _lib.ptr(counts),
+                                      C.byref(used), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    return counts, int(used.value)
+
+
+def sir_torch(G, seed_set, beta, gamma, sims=10000, T=20, rng_seed=None, coins=None):
+    """Monte-Carlo SIR label generator, reference ode_nn.py:30-88.
+
+    Returns (S, I, R) numpy float64 COUNTS of shape [1, T, n] exactly like the
+    reference (callers divide by `sims`, ode_nn_ngraph_sim.py:199); row 0 of S and
+    I holds the initial state once (the reference assigns it, :55-56).
+
+    Coins: by default counter-based Philox keyed by (edge|node, step, sim), seeded
+    from torch's CPU generator so `torch.manual_seed` governs reproducibility as it
+    does for the reference's `torch.rand` (:65,:70).  `coins=` (a recorded stream)
+    switches to the bit-exact parity mode.
+    """
+    n = G.number_of_nodes()
+    e = _edge_arrays(G)
+    if coins is not None:
+        table = np.empty((2 * e.shape[0], 2), dtype=np.int64)     # reference :32-38
+        table[0::2, 0], table[0::2, 1] = e[:, 0], e[:, 1]
+        table[1::2, 0], table[1::2, 1] = e[:, 1], e[:, 0]
+        counts, _ = sir_counts_coins(n, table, seed_set, beta, gamma, sims, T, np.asarray(coins))
+    else:
+        if rng_seed is None:
+            rng_seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+        graph = DeviceGraph(*_csr_from_edges(n, e))
+        counts = sir_counts(graph, seed_set, beta, gamma, sims, T, rng_seed)
+    c = counts.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    c = c.astype(np.float64)
+    return c[0][None], c[1][None], c[2][None]
+
+
+def get_sir_t_nodes_torch(x_rk, maxTime, deltaT, count=True):
+    """Row subsample out[i] = x[int(i/deltaT)], reference ode_nn.py:249-261.
+    One device-side index_select instead of maxTime D2H row copies; the result stays
+    on x_rk's device (the reference builds it on the CPU and callers move it back,
+    ode_nn_ngraph_sim.py:234)."""
+    idx = torch.as_tensor([int(i / deltaT) for i in range(int(maxTime))], device=x_rk.device)
+    if count:
+        return torch.sum(x_rk, axis=1).index_select(0, idx)
+    return x_rk.index_select(0, idx)
+
+
+def create_graph(n_nodes, graph_label="none"):
+    """reference ode_nn.py:394-414: pickled networkx graph -> undirected -> largest
+    connected component -> scipy adjacency.  Returns (G, A, 0)."""
+    import networkx as nx
+    if graph_label != "none":
+        with open(graph_label + ".pkl", "rb") as fh:
+            G = pickle.load(fh)
+        G = G.to_undirected()
+        largest_cc = max(nx.connected_components(G), key=len)
+        G = G.subgraph(largest_cc)
+    else:
+        G = nx.fast_gnp_random_graph(n_nodes, 0.2)
+    A = nx.adjacency_matrix(G)
+    return G, A, 0

@@ -1,0 +1,94 @@
+"""Tensor-level entry points over the C ABI (torch is plumbing: memory + streams)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .graph import DeviceGraph
+
+PARAM_KEYS = ("odefunc.linear.weight", "odefunc.linear.bias", "linearS1.weight", "linearS1.bias",
+              "linear3.weight", "linear3.bias", "linearS2.weight", "linearS2.bias")
+
+METHODS = {"euler": 0, "rk4": 1}
+
+
+def time_grid(maxTime, deltaT) -> np.ndarray:
+    """float64 np.arange(0, maxTime, deltaT): reference ode_nn_ngraph_sim.py:110."""
+    return np.arange(0, maxTime, deltaT)
+
+
+def step_sizes(grid: np.ndarray) -> np.ndarray:
+    """fp32 dt_k = t[k+1]-t[k] (a 0-dim float64 tensor times an fp32 state stays fp32)."""
+    g = np.asarray(grid, dtype=np.float64)
+    return np.ascontiguousarray((g[1:] - g[:-1]).astype(np.float32))
+
+
+def subsample_rows(maxTime, deltaT) -> np.ndarray:
+    """Grid rows get_sir_t_nodes_torch keeps: int(i/deltaT), i < maxTime (ode_nn.py:257-259)."""
+    return np.asarray([int(i / deltaT) for i in range(int(maxTime))], dtype=np.int32)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise _lib.GnodeError(f"GN-ODE path is fp32 (got {t.dtype})")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def pack_params(tensors: dict) -> _lib.Params:
+    p = _lib.Params()
+    for k in PARAM_KEYS:
+        t = tensors[k]
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise _lib.GnodeError(f"parameter {k} must be a contiguous fp32 GPU tensor")
+        setattr(p, k.replace(".", "_"), t.data_ptr())
+    return p
+
+
+def rhs(graph: DeviceGraph, x: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """ODEfunc.forward on x [4*rows, H] (ode_nn_ngraph_sim.py:58-96)."""
+    lib = _lib.load()
+    x = _f32c(x)
+    rows4, H = x.shape
+    if rows4 % 4:
+        raise _lib.GnodeError("state must have 4 slabs")
+    rows = rows4 // 4
+    dx = torch.empty_like(x)
+    ws = _workspace(lib.gnode_rhs_workspace_bytes(rows, H), x.device)
+    _lib.check(lib.gnode_rhs_f32(graph.handle, _lib.ptr(x), _lib.ptr(_f32c(W)), _lib.ptr(_f32c(b)), _lib.ptr(dx), rows, H,
+                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    return dx
+
+
+def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray, method: str = "euler",
+            out_rows: np.ndarray | None = None, want_sol: bool = False, workspace: torch.Tensor | None = None):
+    """ODEBlock.forward on x2d [rows, 3+H]; returns (S, I, R) each [n_out, rows] and sol or None."""
+    lib = _lib.load()
+    x2d = _f32c(x2d)
+    rows, H = x2d.shape[0], x2d.shape[1] - 3
+    dts = np.ascontiguousarray(dts, dtype=np.float32)
+    n_steps = int(dts.shape[0])
+    m = METHODS[method]
+    if out_rows is not None:
+        out_rows = np.ascontiguousarray(out_rows, dtype=np.int32)
+        n_out = int(out_rows.shape[0])
+    else:
+        n_out = n_steps + 1
+    dev = x2d.device
+    out = torch.empty((3, n_out, rows), dtype=torch.float32, device=dev)
+    sol = torch.empty((n_steps + 1, 4 * rows, H), dtype=torch.float32, device=dev) if want_sol else None
+    need = lib.gnode_forward_workspace_bytes(rows, H, m)
+    ws = workspace if (workspace is not None and workspace.numel() >= need) else _workspace(need, dev)
+    p = pack_params(params)
+    _lib.check(lib.gnode_forward_f32(
+        graph.handle, _lib.ptr(x2d), C.byref(p), _lib.host_ptr(dts), n_steps, m,
+        _lib.host_ptr(out_rows) if out_rows is not None else None, n_out,
+        _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(sol) if sol is not None else None,
+        rows, H, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    return out[0], out[1], out[2], sol

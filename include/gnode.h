@@ -1,0 +1,138 @@
+/*
+ * gnode.h -- C ABI of libgnode_hip.so: the MI355X (gfx950) GN-ODE integration path.
+ *
+ * The reference (sissykosm/GN-ODE-SIR) is pure Python and has no FFI of its own;
+ * each entry point below names the reference interface it replaces (file:line
+ * into the reference tree).  INTEGRATION.md shows the ctypes stubs a maintainer
+ * of the reference would add to bind them.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative gnode_status otherwise;
+ *     gnode_last_error() returns a thread-local message for the last failure.
+ *   - "device" pointers are caller-owned HBM allocations (the Python host hands
+ *     over torch tensors' data_ptr()); the library never frees or retains them
+ *     past the call.  "host" pointers are ordinary memory, read before return.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     All work is enqueued on it; nothing synchronises the device except where
+ *     a function says so.  The launch functions do no allocation, so they can be
+ *     captured into a hipGraph by the caller.
+ *   - all floating point is IEEE fp32 (the reference builds its model under
+ *     torch.float32, ode_nn_ngraph_sim.py:433); indices are int32.
+ *   - row layout is the reference's own: a batch of B samples on one graph of n
+ *     nodes is `rows = B*n` rows, row r = b*n + node (ode_nn_ngraph_sim.py:149),
+ *     the adjacency is applied block-diagonally (:68-69) WITHOUT ever building
+ *     the block-diagonal index.  A multi-graph batch (ode_nn_ngraphs.py:179-196)
+ *     is one graph handle holding the concatenated CSR and B = 1.
+ */
+#ifndef GNODE_H
+#define GNODE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GNODE_OK = 0,
+    GNODE_ERR_ARG = -1,      /* bad argument (null pointer, shape mismatch, unsupported H) */
+    GNODE_ERR_HIP = -2,      /* a HIP runtime call failed */
+    GNODE_ERR_WORKSPACE = -3 /* caller workspace too small */
+} gnode_status;
+
+typedef struct gnode_graph_s* gnode_graph_t;
+
+/* Parameters of ODEBlock + ODEfunc, device pointers, names = reference state_dict
+ * keys (ode_nn_ngraph_sim.py:48,123,126,131). */
+typedef struct {
+    const float* odefunc_linear_weight; /* [H,H] row-major (out,in) */
+    const float* odefunc_linear_bias;   /* [H]   */
+    const float* linearS1_weight;       /* [H,1] */
+    const float* linearS1_bias;         /* [H]   */
+    const float* linear3_weight;        /* [4,H] */
+    const float* linear3_bias;          /* [4]   */
+    const float* linearS2_weight;       /* [1,4] */
+    const float* linearS2_bias;         /* [1]   */
+} gnode_params;
+
+const char* gnode_last_error(void);
+int gnode_version(void);
+
+/* ---- graph ---------------------------------------------------------------
+ * Replaces the per-RHS `scipy.sparse.block_diag` + `torch.LongTensor(idx).to(device)`
+ * of ode_nn_ngraph_sim.py:68-71 (ode_nn_ngraphs.py:65-71) and the adjacency
+ * built by create_graph, ode_nn.py:413.  rowptr[n+1] / col[nnz] are HOST int32
+ * CSR arrays (symmetric, sorted columns, values ignored); the handle owns its
+ * device copy.  Synchronous (copies before returning). */
+int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col_host, int32_t n, int64_t nnz,
+                       gnode_graph_t* out);
+int gnode_graph_destroy(gnode_graph_t g);
+int gnode_graph_info(gnode_graph_t g, int32_t* n, int64_t* nnz, int32_t* max_degree);
+
+/* ---- RHS -----------------------------------------------------------------
+ * ODEfunc.forward(t, x): ode_nn_ngraph_sim.py:58-96 (multi: ode_nn_ngraphs.py:54-83).
+ * x, dx: device [4*rows, H], slabs S | I | R | beta-gamma (col 0 beta, col 1 gamma).
+ * workspace: device, >= gnode_rhs_workspace_bytes(rows, H). */
+size_t gnode_rhs_workspace_bytes(int64_t rows, int32_t H);
+int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* b, float* dx,
+                  int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- forward -------------------------------------------------------------
+ * ODEBlock.forward(x): ode_nn_ngraph_sim.py:148-188 (multi: ode_nn_ngraphs.py:124-152)
+ * = encoder + odeint(method='euler' | 'rk4') over the grid + read-out + softmax,
+ * optionally fused with get_sir_t_nodes_torch (ode_nn.py:249-261).
+ *   x          device [rows, 3+H]
+ *   dt_host    host  [n_steps] fp32 step sizes t[k+1]-t[k] (grid has n_steps+1 points)
+ *   method     0 = euler, 1 = rk4 (torchdiffeq's 3/8 rule)
+ *   out_rows_host  host [n_out] ascending grid indices to emit, or NULL = all
+ *                  n_steps+1 points (n_out ignored)
+ *   S, I, R    device [n_out, rows] each (the reference's [G, rows, 1])
+ *   sol        NULL, or device [n_steps+1, 4*rows, H]: the trajectory odeint
+ *              returns (needed by the adjoint backward, never by inference)
+ *   workspace  device, >= gnode_forward_workspace_bytes(rows, H, method) */
+size_t gnode_forward_workspace_bytes(int64_t rows, int32_t H, int32_t method);
+int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
+                      int32_t n_steps, int32_t method, const int32_t* out_rows_host, int32_t n_out,
+                      float* S, float* I, float* R, float* sol, int64_t rows, int32_t H,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Monte-Carlo SIR labels ------------------------------------------------
+ * sir_torch(G, seed_set, beta, gamma, sims, T): ode_nn.py:30-88.
+ *
+ * gnode_sir_mc_philox: production mode.  One workgroup per trajectory; coins are
+ * counter-based Philox4x32-10 keyed by (edge|node, step, sim, kind) so that any
+ * sharding of [sim_offset, sim_offset+sims) over GPUs reproduces the same
+ * counts.  counts: device uint32 [3, T, n] (S, I, R), ACCUMULATED into (caller
+ * zeroes it); rows t >= 1 add one per trajectory per node, row 0 of S and I is
+ * written with the initial state once (reference quirk: assigned, ode_nn.py:55-56).
+ *
+ * gnode_sir_mc_coins: parity mode.  Consumes a recorded coin stream exactly as
+ * the reference consumes torch.rand (ode_nn.py:65,70): per step first one coin
+ * per (infected src -> susceptible dst) row of the directed edge table in table
+ * order, then one per infected node in ascending id.  table_src/table_dst:
+ * device int32 [n_table] (ode_nn.py:32-38 order).  coins: device fp64.
+ * Sequential over sims (one workgroup), writes counts as above and the number
+ * of coins consumed to *coins_used_host after synchronising `stream`. */
+size_t gnode_sir_workspace_bytes(gnode_graph_t g, int32_t T);   /* for gnode_sir_mc_philox */
+size_t gnode_sir_coins_workspace_bytes(void);                    /* for gnode_sir_mc_coins  */
+int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta, double gamma,
+                        int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed, uint32_t* counts,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int gnode_sir_mc_coins(const int32_t* table_src, const int32_t* table_dst, int64_t n_table, int32_t n,
+                       const int32_t* seeds_host, int32_t n_seeds, double beta, double gamma, int64_t sims,
+                       int32_t T, const double* coins, int64_t n_coins, uint32_t* counts,
+                       int64_t* coins_used_host, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- instrumentation -------------------------------------------------------
+ * While enabled, every launch of the two step kernels (0: gather + SIR update +
+ * read-out, 1: node MLP) is bracketed by HIP events on the launch stream;
+ * gnode_profile_read waits for them and returns summed milliseconds and launch
+ * counts.  Used by bench.py's roofline leg; off by default (no overhead). */
+int gnode_profile_enable(int on);
+int gnode_profile_read(double* gather_ms, int64_t* gather_launches, double* mlp_ms, int64_t* mlp_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNODE_H */

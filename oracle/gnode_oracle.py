@@ -31,7 +31,21 @@ from __future__ import annotations
 import numpy as np
 import scipy.sparse as sp
 
+import contextlib
+
 F32 = np.float32
+
+
+@contextlib.contextmanager
+def precision(dtype):
+    """Run the restatement in another working precision (float64 = the exact-arithmetic
+    yardstick used to measure the fp32 noise floor of long integrations)."""
+    global F32
+    old, F32 = F32, dtype
+    try:
+        yield
+    finally:
+        F32 = old
 
 
 # --------------------------------------------------------------------------- graphs

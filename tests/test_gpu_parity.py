@@ -1,0 +1,352 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors the
+reference produced and against the CPU oracle on the same seeded inputs.
+
+Tolerance: 1e-5 relative (to the tensor's max magnitude) for fp32, as north_star
+states; bit-exact for the integer Monte-Carlo counts.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gnode import _lib
+    _lib.load()                       # fails loudly if libgnode_hip.so is missing
+    return torch.device("cuda:0")
+
+
+def _load(path):
+    d = dict(np.load(path))
+    return d, {k[2:]: d[k] for k in d if k.startswith("P:")}
+
+
+def _cases(prefix):
+    return sorted(glob.glob(os.path.join(GOLD, prefix + "*.npz")))
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30)
+
+
+def _tp(P, dev):
+    import torch
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in P.items()}
+
+
+# ------------------------------------------------------------------ A1: ODEfunc.forward
+@pytest.mark.parametrize("path", _cases("rhs_single_"), ids=os.path.basename)
+def test_rhs_single_golden(path, dev):
+    import torch
+    import gnode_oracle as O
+    from gnode import ops
+    from gnode.graph import DeviceGraph
+    d, P = _load(path)
+    rp, ci = O.csr_from_edges(int(d["n"]), d["edges"])
+    g = DeviceGraph(rp, ci)
+    p = _tp(P, dev)
+    dx = ops.rhs(g, torch.from_numpy(d["x"]).to(dev), p["odefunc.linear.weight"], p["odefunc.linear.bias"]).cpu().numpy()
+    assert _rel(dx, d["dx"]) <= RTOL
+    q = dx.shape[0] // 4
+    assert not dx[3 * q:].any()
+
+
+def test_rhs_module_surface(dev):
+    """ODEfunc(A, beta, gamma, hidden1, device).forward(t, x) keeps the reference signature."""
+    import torch
+    import scipy.sparse as sp
+    import gnode_oracle as O
+    from gnode.ode_nn_ngraph_sim import ODEfunc
+    d, P = _load(_cases("rhs_single_karate_B2_H8")[0])
+    n = int(d["n"])
+    rp, ci = O.csr_from_edges(n, d["edges"])
+    A = sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n))
+    f = ODEfunc(A, 0.2, 0.1, 8, dev).to(dev)
+    assert set(f.state_dict().keys()) == {"ln.weight", "ln.bias", "linear.weight", "linear.bias"}
+    f.linear.weight.data.copy_(torch.from_numpy(P["odefunc.linear.weight"]))
+    f.linear.bias.data.copy_(torch.from_numpy(P["odefunc.linear.bias"]))
+    dx = f(torch.tensor(0.0), torch.from_numpy(d["x"]).to(dev))
+    assert _rel(dx.cpu().numpy(), d["dx"]) <= RTOL
+
+
+# ------------------------------------------------------------------ A3/A4/A5: ODEBlock.forward
+@pytest.mark.parametrize("path", _cases("fwd_single_"), ids=os.path.basename)
+def test_forward_single_golden(path, dev):
+    import torch
+    import scipy.sparse as sp
+    import gnode_oracle as O
+    from gnode.ode_nn_ngraph_sim import ODEfunc, ODEBlock
+    from gnode.ode_nn import get_sir_t_nodes_torch
+    from gnode import ops
+    d, P = _load(path)
+    n, H = int(d["n"]), d["x"].shape[2] - 3
+    maxTime, deltaT = int(d["maxTime"]), float(d["deltaT"])
+    rp, ci = O.csr_from_edges(n, d["edges"])
+    A = sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n))
+    f = ODEfunc(A, 0.2, 0.1, H, dev)
+    m = ODEBlock(maxTime, deltaT, n, [0], H, f, dev).to(dev)
+    want_keys = {"odefunc.ln.weight", "odefunc.ln.bias", "odefunc.linear.weight", "odefunc.linear.bias",
+                 "linearS1.weight", "linearS1.bias", "ln.weight", "ln.bias", "linear3.weight", "linear3.bias",
+                 "linearS2.weight", "linearS2.bias"}
+    assert set(m.state_dict().keys()) == want_keys
+    m.load_state_dict({**m.state_dict(), **{k: torch.from_numpy(v) for k, v in P.items()}})
+    x = torch.from_numpy(d["x"]).to(dev)
+    with torch.no_grad():
+        S, I, R = m(x)
+    for got, want in ((S, d["S"]), (I, d["I"]), (R, d["R"])):
+        assert tuple(got.shape) == want.shape
+        assert _rel(got.cpu().numpy(), want) <= RTOL
+    sub = get_sir_t_nodes_torch(torch.squeeze(S, -1), maxTime, deltaT, count=False)
+    assert _rel(sub.cpu().numpy(), d["S_sub"]) <= RTOL
+    # fused subsample == subsample of the full output, exactly
+    with torch.no_grad():
+        S2, _, _ = m(x, out_rows=ops.subsample_rows(maxTime, deltaT))
+    assert torch.equal(S2.squeeze(-1), sub)
+    if "loss" in d:
+        loss = O.l1_loss(S.cpu().numpy(), I.cpu().numpy(), R.cpu().numpy(), d["y"], maxTime, deltaT)
+        assert abs(loss - float(d["loss"])) <= 1e-6
+
+
+@pytest.mark.parametrize("path", _cases("multi_"), ids=os.path.basename)
+def test_multi_graph_golden(path, dev):
+    import torch
+    import scipy.sparse as sp
+    import gnode_oracle as O
+    from gnode.ode_nn_ngraphs import ODEfunc, ODEBlock
+    d, P = _load(path)
+    H = d["x"].shape[1] - 3
+    A_list = []
+    for j in range(3):
+        n = int(d[f"n{j}"])
+        rp, ci = O.csr_from_edges(n, d[f"edges{j}"])
+        A_list.append(sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n)))
+    f = ODEfunc(A_list, H, dev)
+    m = ODEBlock(int(d["maxTime"]), float(d["deltaT"]), H, f, dev).to(dev)
+    m.load_state_dict({**m.state_dict(), **{k: torch.from_numpy(v) for k, v in P.items()}})
+    dst = f(torch.tensor(0.0), torch.from_numpy(d["state"]).to(dev))
+    assert _rel(dst.cpu().numpy(), d["dstate"]) <= RTOL
+    with torch.no_grad():
+        S, I, R = m(torch.from_numpy(d["x"]).to(dev))
+    for got, want in ((S, d["S"]), (I, d["I"]), (R, d["R"])):
+        assert tuple(got.shape) == want.shape
+        assert _rel(got.cpu().numpy(), want) <= RTOL
+
+
+def _truth64(x, P, rp, ci, maxTime, deltaT, method):
+    """The same algorithm in float64: the yardstick for fp32 noise on long horizons."""
+    import gnode_oracle as O
+    with O.precision(np.float64):
+        P64 = {k: v.astype(np.float64) for k, v in P.items()}
+        return O.odeblock_forward_single(x.astype(np.float64), P64, rp, ci, maxTime, deltaT, method=method)
+
+
+@pytest.mark.parametrize("n,m,B,H,maxTime,deltaT,method", [
+    (1893, 13835, 4, 64, 30, 0.5, "euler"),     # fb-social sized (config 2), full 59-step horizon
+    (7066, 100736, 1, 64, 30, 0.5, "euler"),    # wiki-vote sized (config 3)
+    (500, 3000, 3, 32, 8, 0.5, "euler"),        # generic (non-MFMA) node-MLP path
+    (500, 3000, 2, 24, 6, 0.25, "euler"),       # H not a power of two
+    (333, 1500, 5, 128, 4, 0.5, "euler"),
+    (400, 2000, 2, 64, 6, 0.5, "rk4"),
+    (400, 2000, 2, 16, 6, 0.5, "rk4"),
+])
+def test_forward_vs_oracle(n, m, B, H, maxTime, deltaT, method, dev):
+    """Tolerance: 1e-5 relative-to-scale against the fp32 CPU oracle on horizons where fp32
+    itself is reproducible to that level (<= 20 Euler steps here).  The SIR dynamics amplify
+    rounding differences (x2 every ~6 steps on these graphs): at 59 steps two CPU fp32
+    restatements (numpy vs C) already differ by 1.8e-5 and sit 2e-5 from the float64
+    result, so there the bar is the fp32 NOISE FLOOR: the GPU must be no further from the
+    float64 result than 2x the CPU fp32 oracle is (and never worse than 1e-4)."""
+    import torch
+    import gnode_oracle as O
+    import oracle_c as OC
+    from gnode import ops
+    from gnode.graph import DeviceGraph
+    rp, ci, _ = O.er_graph(n, m, seed=n)
+    P = O.init_params(H, seed=H)
+    x = O.make_samples(n, B, H, seed=B)
+    grid = O.time_grid(maxTime, deltaT)
+    if method == "euler":
+        want = OC.forward_euler(rp, ci, n, x, P, O.step_sizes(grid))
+    else:
+        want = O.odeblock_forward_single(x, P, rp, ci, maxTime, deltaT, method="rk4")
+    g = DeviceGraph(rp, ci)
+    S, I, R, _ = ops.forward(g, torch.from_numpy(x).to(dev).reshape(B * n, 3 + H), _tp(P, dev), ops.step_sizes(grid), method)
+    got = [t.cpu().numpy() for t in (S, I, R)]
+    if grid.shape[0] - 1 <= 20:
+        for a, w in zip(got, want):
+            assert _rel(a, w[..., 0]) <= RTOL
+    else:
+        truth = _truth64(x, P, rp, ci, maxTime, deltaT, method)
+        for a, w, t in zip(got, want, truth):
+            floor = _rel(w[..., 0], t[..., 0])
+            err = _rel(a, t[..., 0])
+            print(f"fp32 oracle vs f64: {floor:.2e}   gpu vs f64: {err:.2e}   gpu vs fp32 oracle: {_rel(a, w[..., 0]):.2e}")
+            assert err <= max(RTOL, 2.0 * floor) and err <= 1e-4
+            # and the first 20 steps, where fp32 is reproducible, meet the plain 1e-5 bar
+            assert _rel(a[:21], w[:21, :, 0]) <= RTOL
+    s = got[0] + got[1] + got[2]
+    assert np.max(np.abs(s - 1.0)) < 1e-5
+
+
+def test_forward_sol_matches_states(dev):
+    """sol (what odeint returns) is consistent with the fused outputs and with the oracle."""
+    import torch
+    import gnode_oracle as O
+    from gnode import ops
+    from gnode.graph import DeviceGraph
+    n, B, H = 150, 2, 64
+    rp, ci, _ = O.er_graph(n, 600, seed=9)
+    P = O.init_params(H, seed=3)
+    x = O.make_samples(n, B, H, seed=1)
+    g = DeviceGraph(rp, ci)
+    S, I, R, sol = ops.forward(g, torch.from_numpy(x).to(dev).reshape(B * n, 3 + H), _tp(P, dev),
+                               ops.step_sizes(ops.time_grid(5, 0.5)), want_sol=True)
+    So, Io, Ro, sol_o = O.odeblock_forward_single(x, P, rp, ci, 5, 0.5, return_sol=True)
+    assert tuple(sol.shape) == sol_o.shape
+    assert _rel(sol.cpu().numpy(), sol_o) <= RTOL
+    assert np.array_equal(sol[:, 3 * B * n:].cpu().numpy(), sol_o[:, 3 * B * n:])   # beta-gamma slab rides along
+
+
+def test_block_diagonal_independence(dev):
+    """Samples of a batch never mix: a batched forward equals per-sample forwards bit for bit."""
+    import torch
+    import gnode_oracle as O
+    from gnode import ops
+    from gnode.graph import DeviceGraph
+    n, B, H = 700, 4, 64
+    rp, ci, _ = O.er_graph(n, 4000, seed=21)
+    P = _tp(O.init_params(H, seed=5), dev)
+    x = torch.from_numpy(O.make_samples(n, B, H, seed=2)).to(dev)
+    g = DeviceGraph(rp, ci)
+    dts = ops.step_sizes(ops.time_grid(6, 0.5))
+    S, I, R, _ = ops.forward(g, x.reshape(B * n, 3 + H), P, dts)
+    for b in range(B):
+        Sb, Ib, Rb, _ = ops.forward(g, x[b].contiguous(), P, dts)
+        assert torch.equal(S[:, b * n:(b + 1) * n], Sb) and torch.equal(I[:, b * n:(b + 1) * n], Ib)
+
+
+def test_edge_cases(dev):
+    """Isolated nodes (empty CSR rows), a hub row longer than one index chunk, zero steps."""
+    import torch
+    import gnode_oracle as O
+    from gnode import ops
+    from gnode.graph import DeviceGraph
+    n, H = 130, 64
+    edges = [(0, j) for j in range(1, 100)] + [(100, 101)]       # hub of degree 99; nodes 102..129 isolated
+    rp, ci = O.csr_from_edges(n, edges)
+    P = O.init_params(H, seed=8)
+    x = O.make_samples(n, 2, H, seed=4)
+    g = DeviceGraph(rp, ci)
+    S, I, R, _ = ops.forward(g, torch.from_numpy(x).to(dev).reshape(2 * n, 3 + H), _tp(P, dev),
+                             ops.step_sizes(ops.time_grid(4, 0.5)))
+    So, Io, Ro = O.odeblock_forward_single(x, P, rp, ci, 4, 0.5)
+    assert max(_rel(S.cpu().numpy(), So[..., 0]), _rel(I.cpu().numpy(), Io[..., 0])) <= RTOL
+    S0, _, _, _ = ops.forward(g, torch.from_numpy(x).to(dev).reshape(2 * n, 3 + H), _tp(P, dev), np.zeros(0, np.float32))
+    assert tuple(S0.shape) == (1, 2 * n)
+    assert _rel(S0.cpu().numpy(), So[:1, :, 0]) <= RTOL
+
+
+def test_bad_arguments_raise(dev):
+    import torch
+    import gnode_oracle as O
+    from gnode import ops, GnodeError
+    from gnode.graph import DeviceGraph
+    rp, ci, _ = O.er_graph(50, 100, seed=1)
+    g = DeviceGraph(rp, ci)
+    P = _tp(O.init_params(64), dev)
+    with pytest.raises(GnodeError):   # rows not a multiple of n
+        ops.forward(g, torch.zeros(75, 67, device=dev), P, np.zeros(2, np.float32))
+    with pytest.raises(GnodeError):   # H % 4 != 0
+        ops.forward(g, torch.zeros(50, 3 + 6, device=dev), _tp(O.init_params(6), dev), np.zeros(2, np.float32))
+    with pytest.raises(GnodeError):   # CPU tensor
+        ops.forward(g, torch.zeros(50, 67), P, np.zeros(2, np.float32))
+
+
+# ------------------------------------------------------------------ A8: sir_torch
+@pytest.mark.parametrize("path", _cases("sir_"), ids=os.path.basename)
+def test_sir_recorded_coins_bit_exact(path, dev):
+    """Integer infection state under the reference's own coin stream: bit-exact."""
+    import gnode_oracle as O
+    from gnode.ode_nn import sir_counts_coins
+    d, _ = _load(path)
+    table = O.edge_table(d["edges"])
+    counts, used = sir_counts_coins(int(d["n"]), table, d["seeds"].tolist(), float(d["beta"]), float(d["gamma"]),
+                                    int(d["sims"]), int(d["T"]), d["coins"])
+    assert used == d["coins"].shape[0]
+    c = counts.cpu().numpy().astype(np.float64)
+    assert np.array_equal(c[0][None], d["S"]) and np.array_equal(c[1][None], d["I"]) and np.array_equal(c[2][None], d["R"])
+
+
+def test_sir_torch_surface_with_coins(dev):
+    import networkx as nx
+    from gnode.ode_nn import sir_torch
+    d, _ = _load(_cases("sir_karate")[0])
+    G = nx.Graph()
+    G.add_nodes_from(range(int(d["n"])))
+    G.add_edges_from(d["edges"].tolist())
+    assert np.array_equal(np.asarray(list(G.edges())), d["edges"])
+    S, I, R = sir_torch(G, d["seeds"].tolist(), float(d["beta"]), float(d["gamma"]), int(d["sims"]), int(d["T"]),
+                        coins=d["coins"])
+    assert S.shape == d["S"].shape and S.dtype == np.float64
+    assert np.array_equal(S, d["S"]) and np.array_equal(I, d["I"]) and np.array_equal(R, d["R"])
+
+
+@pytest.mark.parametrize("n,m,sims,T", [(34, 78, 500, 20), (1000, 6000, 300, 15), (7066, 100736, 64, 20)])
+def test_sir_philox_bit_exact_vs_oracle(n, m, sims, T, dev):
+    import gnode_oracle as O
+    import oracle_c as OC
+    from gnode.graph import DeviceGraph
+    from gnode.ode_nn import sir_counts
+    rp, ci, _ = O.er_graph(n, m, seed=m)
+    seeds = [1, n // 2]
+    g = DeviceGraph(rp, ci)
+    got = sir_counts(g, seeds, 0.3, 0.2, sims, T, rng_seed=0xABCDEF0123, sim_offset=11).cpu().numpy().astype(np.uint32)
+    want = OC.sir_philox(n, rp, ci, seeds, 0.3, 0.2, sims, T, rng_seed=0xABCDEF0123, sim_offset=11)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[0, 1:] + got[1, 1:] + got[2, 1:], np.full((T - 1, n), sims, np.uint32))
+
+
+def test_sir_philox_sharded_equals_whole(dev):
+    """Sharding the sims range (what multi-GPU does) reproduces the single-call counts exactly."""
+    import gnode_oracle as O
+    from gnode.graph import DeviceGraph
+    from gnode.ode_nn import sir_counts
+    rp, ci, _ = O.er_graph(400, 2400, seed=3)
+    g = DeviceGraph(rp, ci)
+    whole = sir_counts(g, [7], 0.4, 0.1, 1000, 12, rng_seed=5)
+    acc = sir_counts(g, [7], 0.4, 0.1, 600, 12, rng_seed=5, sim_offset=0)
+    acc = sir_counts(g, [7], 0.4, 0.1, 400, 12, rng_seed=5, sim_offset=600, counts=acc)
+    import torch
+    assert torch.equal(whole, acc)
+
+
+def test_sir_torch_statistics(dev):
+    """Default (Philox) sir_torch agrees with the reference-stream model within MC error and
+    keeps the reference's output contract ([1,T,n] float64 counts, row-0 quirk)."""
+    import networkx as nx
+    import torch
+    import gnode_oracle as O
+    from gnode.ode_nn import sir_torch
+    G = nx.karate_club_graph()
+    sims, T = 4000, 12
+    torch.manual_seed(0)
+    S, I, R = sir_torch(G, [0, 33], 0.3, 0.2, sims, T)
+    assert S.shape == (1, T, 34) and S.dtype == np.float64
+    assert S[0, 0].sum() == 32 and I[0, 0].sum() == 2 and R[0, 0].sum() == 0
+    e = np.asarray(list(G.edges()))
+    rng = np.random.default_rng(1)
+    So, Io, Ro, _, _ = O.sir_coins(34, O.edge_table(e), [0, 33], 0.3, 0.2, sims, T, rng.random(20_000_000))
+    for a, b in ((S, So), (I, Io), (R, Ro)):
+        dd = np.abs(a[0, 1:] - b[0, 1:]) / sims
+        assert dd.max() < 0.05 and dd.mean() < 0.01
