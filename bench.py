@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--edges", type=int, default=500000)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--samples", type=int, default=8, help="samples per GPU")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("GNODE_CHUNK", "1")),
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("GNODE_CHUNK", "8")),
                     help="samples integrated together per launch sequence")
     ap.add_argument("--maxTime", type=int, default=30)
     ap.add_argument("--deltaT", type=float, default=0.5)
@@ -145,7 +145,7 @@ def main():
                    "samples_per_gpu": B, "samples_per_launch": chunk, "euler_steps": n_steps,
                    "parallelism": f"sample-sharded x{world}, no data-path collective", "outputs_valid": ok},
         "node_maxTime_per_s": world * B * n * args.maxTime * args.steps / elapsed,
-        "roofline": {"bound": "hbm", "kernel": "k_gather<16,1> (CSR pull-gather + SIR update + read-out)",
+        "roofline": {"bound": "hbm", "kernel": "k_step64<true> (CSR pull-gather + MFMA node MLP + SIR update + read-out, one launch per Euler step)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "avg_launch_us": gather_avg_s * 1e6, "launches": int(gcnt.value),
                      "algorithmic_bytes_per_launch": alg_bytes,

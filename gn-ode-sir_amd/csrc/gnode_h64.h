@@ -1,0 +1,13 @@
+// H = 64 fast path launchers (gnode_h64.hip), used by the C-ABI host code in gnode_ode.hip.
+#pragma once
+#include "gnode_common.h"
+
+struct Step64Out {
+    float* S; float* I; float* R;   // this step's output rows [rows], or null
+    float* sol;                     // sol[g+1] base ([4*rows, 64]), or null
+};
+
+int gn_launch_mlp64(const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st);
+int gn_launch_step64(const gnode_graph_s* g, long rows, float* Y, const float* ZI, float* ZI_next, const float* W,
+                     const float* bias, const float* beta, const float* gamma, float dt, const gnode_params* p,
+                     Step64Out out, bool fuse, hipStream_t st);

@@ -1,0 +1,319 @@
+// H = 64 fast path of the GN-ODE step for MI355X (gfx950).
+//
+// One launch per Euler step (per chunk of samples):
+//   k_step64<FUSE>  persistent 256-thread workgroups walk 32-node tiles:
+//     P1  stage the tile's Y_S rows to LDS (coalesced 16 B/lane, 4 rows per wave
+//         instruction) and pull-gather AI = sum_{c in adj} Z_I[c] with one 16-lane
+//         group per row (column indices broadcast inside the group by DPP
+//         row_newbcast, neighbour rows as 256-B coalesced reads);
+//     P2  Z_S = sigmoid(Y_S W^T + b) on the fp32 matrix cores
+//         (v_mfma_f32_16x16x4_f32, exact fp32), W^T resident in LDS for the
+//         whole launch, each wave a 32x16 slab of the tile's output;
+//     P3  SIR derivative + Euler update of Y_S, Y_I, Y_R in place, optional
+//         trajectory write, fused read-out head + 3-way softmax (16-lane DPP
+//         reductions, no LDS traffic);
+//     P4  (FUSE) Z_I of the NEXT step from the freshly updated Y_I rows, again on
+//         the matrix cores, so the separate node-MLP launch disappears and
+//         Y_S / Y_I are read once per step.
+//   k_mlp64          the same MFMA tile engine alone (RHS API, step 0, RK4 stages).
+//
+// Reference semantics: ode_nn_ngraph_sim.py:58-96 (RHS), :168 (euler), :172-187 (head).
+#include "gnode_common.h"
+#include "gnode_h64.h"
+#include <algorithm>
+#include <cstdlib>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TS 68            // LDS row stride in floats (272 B): 16-B aligned rows, spreads banks
+#define TILE_ROWS 32
+
+__device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ---- DPP helpers: a 16-lane group is exactly one DPP row -----------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+// sum over the 16 lanes of a row, result in every lane: mirror, half-mirror, xor2, xor1
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_f<0x140>(v);   // row_mirror        i <-> 15-i
+    v += dpp_f<0x141>(v);   // row_half_mirror   i <-> 7-i within each half
+    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+    return v;
+}
+// lane J of the row broadcast to the whole row
+template <int J>
+__device__ __forceinline__ int row_bcast(int v) { return dpp_i<0x150 + J>(v); }
+
+// ---- pull-gather of one row by a 16-lane group ---------------------------------------
+// ascending-column accumulation order = the CPU scatter_add_ order of the reference.
+__device__ __forceinline__ float4 gather_row64(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                               const float* __restrict__ ZI_base, int node, bool valid, int sub) {
+    float4 acc = zero4();
+    int start = 0, end = 0;
+    if (valid) { start = rowptr[node]; end = rowptr[node + 1]; }
+    for (int e0 = start; e0 < end; e0 += 16) {
+        const int cnt = min(16, end - e0);
+        const int mine = (sub < cnt) ? col[e0 + sub] : 0;
+#define GN_G4(J)                                                                               \
+        if (J < cnt) {                                                                         \
+            const int c0 = row_bcast<J>(mine), c1 = row_bcast<J + 1>(mine);                    \
+            const int c2 = row_bcast<J + 2>(mine), c3 = row_bcast<J + 3>(mine);                \
+            float4 v0 = ld4g(ZI_base + (size_t)c0 * 64 + 4 * sub), v1 = zero4(), v2 = v1, v3 = v1; \
+            if (J + 1 < cnt) v1 = ld4g(ZI_base + (size_t)c1 * 64 + 4 * sub);                   \
+            if (J + 2 < cnt) v2 = ld4g(ZI_base + (size_t)c2 * 64 + 4 * sub);                   \
+            if (J + 3 < cnt) v3 = ld4g(ZI_base + (size_t)c3 * 64 + 4 * sub);                   \
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;                        \
+            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;                        \
+            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;                        \
+            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;                        \
+        }
+        GN_G4(0) GN_G4(4) GN_G4(8) GN_G4(12)
+#undef GN_G4
+    }
+    return acc;
+}
+
+// ---- MFMA tile engine: out[32][64] = sigmoid(X[32][64] W^T + b) -----------------------
+// X in LDS tile Tin, W in LDS Wl ([64][TS]), result written to LDS tile Tout as [row][feature].
+// Wave w owns output features [16w, 16w+16).  v_mfma_f32_16x16x4_f32 operand maps:
+//   A[i][k'] / B[k'][j]: i = j = lane & 15, k' = lane >> 4;  D: col = lane & 15, row = 4*(lane>>4) + reg.
+// k is visited as kappa = 16*(lane>>4) + 4m + c so every fragment fetch is one ds_read_b128.
+__device__ __forceinline__ void mfma_tile(const float* __restrict__ Tin, const float* __restrict__ Wl,
+                                          float* __restrict__ Tout, float bias_l, int w, int lane) {
+    const int i = lane & 15, kq = lane >> 4;
+    f32x4 acc0 = {bias_l, bias_l, bias_l, bias_l}, acc1 = acc0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float4 b = *reinterpret_cast<const float4*>(Wl + (16 * w + i) * TS + 16 * kq + 4 * m);
+        const float4 a0 = *reinterpret_cast<const float4*>(Tin + i * TS + 16 * kq + 4 * m);
+        const float4 a1 = *reinterpret_cast<const float4*>(Tin + (16 + i) * TS + 16 * kq + 4 * m);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Tout[(4 * kq + r) * TS + 16 * w + i] = sigmoid_f(acc0[r]);
+        Tout[(16 + 4 * kq + r) * TS + 16 * w + i] = sigmoid_f(acc1[r]);
+    }
+}
+
+__device__ __forceinline__ void load_W_to_lds(const float* __restrict__ W, float* __restrict__ Wl) {
+    // 64x64 floats = 1024 float4: 4 per thread, coalesced
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = q * 256 + threadIdx.x;      // float4 index
+        const int r = idx >> 4, c4 = idx & 15;
+        *reinterpret_cast<float4*>(Wl + r * TS + 4 * c4) = ld4g(W + (size_t)idx * 4);
+    }
+}
+
+// --------------------------------------------------------------------------- k_mlp64
+__global__ __launch_bounds__(256) void k_mlp64(const float* __restrict__ X, const float* __restrict__ W,
+                                               const float* __restrict__ bias, float* __restrict__ Z, long nrows) {
+    __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
+    __shared__ __attribute__((aligned(16))) float T[TILE_ROWS * TS];
+    __shared__ __attribute__((aligned(16))) float T2[TILE_ROWS * TS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
+    load_W_to_lds(W, Wl);
+    const float bias_l = bias[16 * w + (lane & 15)];
+    const long ntiles = (nrows + TILE_ROWS - 1) / TILE_ROWS;
+    const int lr0 = w * 8 + g, lr1 = w * 8 + 4 + g;
+    long t = blockIdx.x;
+    float4 x0 = zero4(), x1 = zero4();
+    if (t < ntiles) {
+        const long r0 = t * TILE_ROWS + lr0, r1 = t * TILE_ROWS + lr1;
+        if (r0 < nrows) x0 = ld4g(X + (size_t)r0 * 64 + 4 * sub);
+        if (r1 < nrows) x1 = ld4g(X + (size_t)r1 * 64 + 4 * sub);
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        *reinterpret_cast<float4*>(T + lr0 * TS + 4 * sub) = x0;
+        *reinterpret_cast<float4*>(T + lr1 * TS + 4 * sub) = x1;
+        const long tn = t + gridDim.x;                 // prefetch the next tile under the MFMAs
+        x0 = zero4(); x1 = zero4();
+        if (tn < ntiles) {
+            const long r0 = tn * TILE_ROWS + lr0, r1 = tn * TILE_ROWS + lr1;
+            if (r0 < nrows) x0 = ld4g(X + (size_t)r0 * 64 + 4 * sub);
+            if (r1 < nrows) x1 = ld4g(X + (size_t)r1 * 64 + 4 * sub);
+        }
+        __syncthreads();
+        mfma_tile(T, Wl, T2, bias_l, w, lane);
+        __syncthreads();
+        const long r0 = t * TILE_ROWS + lr0, r1 = t * TILE_ROWS + lr1;
+        if (r0 < nrows) st4g(Z + (size_t)r0 * 64 + 4 * sub, *reinterpret_cast<const float4*>(T2 + lr0 * TS + 4 * sub));
+        if (r1 < nrows) st4g(Z + (size_t)r1 * 64 + 4 * sub, *reinterpret_cast<const float4*>(T2 + lr1 * TS + 4 * sub));
+    }
+}
+
+// --------------------------------------------------------------------------- k_step64
+__device__ __forceinline__ void readout64(float4 yS, float4 yI, float4 yR, int sub, const float* __restrict__ w3,
+                                          const float* __restrict__ b3, const float* __restrict__ w2,
+                                          const float* __restrict__ b2, float& pS, float& pI, float& pR) {
+    float qS = b2[0], qI = qS, qR = qS;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 wv = ld4g(w3 + k * 64 + 4 * sub);
+        float s = fmaf(wv.x, yS.x, fmaf(wv.y, yS.y, fmaf(wv.z, yS.z, wv.w * yS.w)));
+        float i = fmaf(wv.x, yI.x, fmaf(wv.y, yI.y, fmaf(wv.z, yI.z, wv.w * yI.w)));
+        float r = fmaf(wv.x, yR.x, fmaf(wv.y, yR.y, fmaf(wv.z, yR.z, wv.w * yR.w)));
+        s = row_sum16(s) + b3[k];
+        i = row_sum16(i) + b3[k];
+        r = row_sum16(r) + b3[k];
+        qS = fmaf(w2[k], fmaxf(s, 0.f), qS);
+        qI = fmaf(w2[k], fmaxf(i, 0.f), qI);
+        qR = fmaf(w2[k], fmaxf(r, 0.f), qR);
+    }
+    const float m = fmaxf(qS, fmaxf(qI, qR));
+    const float eS = __expf(qS - m), eI = __expf(qI - m), eR = __expf(qR - m);
+    const float inv = 1.0f / (eS + eI + eR);
+    pS = eS * inv; pI = eI * inv; pR = eR * inv;
+}
+
+template <bool FUSE>
+__global__ __launch_bounds__(256) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+                                                long rows, int tiles_per_sample, long total_tiles,
+                                                float* __restrict__ Y, const float* __restrict__ ZI,
+                                                float* __restrict__ ZI_next, const float* __restrict__ W,
+                                                const float* __restrict__ bias, const float* __restrict__ beta,
+                                                const float* __restrict__ gamma, float dt,
+                                                const float* __restrict__ w3, const float* __restrict__ b3,
+                                                const float* __restrict__ w2, const float* __restrict__ b2,
+                                                Step64Out out) {
+    __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
+    __shared__ __attribute__((aligned(16))) float T[TILE_ROWS * TS];
+    __shared__ __attribute__((aligned(16))) float T2[TILE_ROWS * TS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
+    load_W_to_lds(W, Wl);
+    const float bias_l = bias[16 * w + (lane & 15)];
+    const size_t slab = (size_t)rows * 64;
+    float* YS = Y; float* YI = Y + slab; float* YR = Y + 2 * slab;
+    const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
+
+    for (long t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const long b = t / tiles_per_sample;
+        const int tile = (int)(t - b * tiles_per_sample);
+        const long base = b * n;
+        int node[2]; bool valid[2]; size_t off[2];
+        float4 ys[2], ai[2], yi[2], yr[2], zi[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            node[p] = tile * TILE_ROWS + lr[p];
+            valid[p] = node[p] < n;
+            off[p] = (size_t)(base + node[p]) * 64 + 4 * sub;
+            ys[p] = valid[p] ? ld4g(YS + off[p]) : zero4();
+        }
+        // -------- P1: stage Y_S, issue own-row loads, gather
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *reinterpret_cast<float4*>(T + lr[p] * TS + 4 * sub) = ys[p];
+            yi[p] = valid[p] ? ld4g(YI + off[p]) : zero4();
+            yr[p] = valid[p] ? ld4g(YR + off[p]) : zero4();
+            zi[p] = valid[p] ? ld4g(ZI + off[p]) : zero4();
+        }
+        ai[0] = gather_row64(rowptr, col, ZI + (size_t)base * 64, node[0], valid[0], sub);
+        ai[1] = gather_row64(rowptr, col, ZI + (size_t)base * 64, node[1], valid[1], sub);
+        __syncthreads();
+        // -------- P2: Z_S on the matrix cores
+        mfma_tile(T, Wl, T2, bias_l, w, lane);
+        __syncthreads();
+        // -------- P3: SIR derivative (ode_nn_ngraph_sim.py:75-77), Euler update, read-out
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float4 zs = *reinterpret_cast<const float4*>(T2 + lr[p] * TS + 4 * sub);
+            float nb = 0.f, gm = 0.f;
+            if (valid[p]) { nb = -beta[base + node[p]]; gm = gamma[base + node[p]]; }
+            float4 dS, dI, dR;
+            dS.x = nb * (ai[p].x * zs.x); dS.y = nb * (ai[p].y * zs.y); dS.z = nb * (ai[p].z * zs.z); dS.w = nb * (ai[p].w * zs.w);
+            dR.x = gm * zi[p].x; dR.y = gm * zi[p].y; dR.z = gm * zi[p].z; dR.w = gm * zi[p].w;
+            dI.x = -dS.x - dR.x; dI.y = -dS.y - dR.y; dI.z = -dS.z - dR.z; dI.w = -dS.w - dR.w;
+            ys[p].x += dt * dS.x; ys[p].y += dt * dS.y; ys[p].z += dt * dS.z; ys[p].w += dt * dS.w;
+            yi[p].x += dt * dI.x; yi[p].y += dt * dI.y; yi[p].z += dt * dI.z; yi[p].w += dt * dI.w;
+            yr[p].x += dt * dR.x; yr[p].y += dt * dR.y; yr[p].z += dt * dR.z; yr[p].w += dt * dR.w;
+            if (valid[p]) {
+                st4g(YS + off[p], ys[p]); st4g(YI + off[p], yi[p]); st4g(YR + off[p], yr[p]);
+                if (out.sol) { st4g(out.sol + off[p], ys[p]); st4g(out.sol + slab + off[p], yi[p]); st4g(out.sol + 2 * slab + off[p], yr[p]); }
+            }
+            if (out.S) {
+                float pS, pI, pR;
+                readout64(ys[p], yi[p], yr[p], sub, w3, b3, w2, b2, pS, pI, pR);
+                if (valid[p] && sub == 0) {
+                    out.S[base + node[p]] = pS; out.I[base + node[p]] = pI; out.R[base + node[p]] = pR;
+                }
+            }
+            if (FUSE) *reinterpret_cast<float4*>(T + lr[p] * TS + 4 * sub) = yi[p];   // stage Y_I' for P4
+        }
+        if (FUSE) {
+            // -------- P4: Z_I of the next step from the updated Y_I rows
+            __syncthreads();
+            mfma_tile(T, Wl, T2, bias_l, w, lane);
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                if (valid[p]) st4g(ZI_next + off[p], *reinterpret_cast<const float4*>(T2 + lr[p] * TS + 4 * sub));
+        }
+        __syncthreads();   // T / T2 are rewritten by the next tile
+    }
+}
+
+// --------------------------------------------------------------------------- host launchers
+// grid sizing knob for experiments: GNODE_WGS_PER_CU = k (persistent grid of k*CUs), 0 = one workgroup per tile
+static int wgs_per_cu() {
+    static const int v = [] { const char* e = getenv("GNODE_WGS_PER_CU"); return e ? atoi(e) : 4; }();
+    return v;
+}
+static int g_num_cu = 0;
+static int num_cus() {
+    if (g_num_cu == 0) {
+        int dev = 0, cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t p;
+            if (hipGetDeviceProperties(&p, dev) == hipSuccess) cu = p.multiProcessorCount;
+        }
+        g_num_cu = cu > 0 ? cu : 256;
+    }
+    return g_num_cu;
+}
+
+int gn_launch_mlp64(const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st) {
+    if (nrows <= 0) return 0;
+    const long ntiles = (nrows + TILE_ROWS - 1) / TILE_ROWS;
+    const int k = wgs_per_cu();
+    const int grid = (int)(k > 0 ? std::min<long>(ntiles, (long)num_cus() * k) : ntiles);
+    hipLaunchKernelGGL(k_mlp64, dim3(grid), dim3(256), 0, st, X, W, b, Z, nrows);
+    GN_LAUNCH_CHECK();
+    return 0;
+}
+
+int gn_launch_step64(const gnode_graph_s* g, long rows, float* Y, const float* ZI, float* ZI_next, const float* W,
+                     const float* bias, const float* beta, const float* gamma, float dt, const gnode_params* p,
+                     Step64Out out, bool fuse, hipStream_t st) {
+    const int tps = (g->n + TILE_ROWS - 1) / TILE_ROWS;
+    const long total = (long)(rows / g->n) * tps;
+    const int k = wgs_per_cu();
+    const int grid = (int)(k > 0 ? std::min<long>(total, (long)num_cus() * k) : total);
+    if (fuse)
+        hipLaunchKernelGGL(k_step64<true>, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI,
+                           ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,
+                           p->linearS2_bias, out);
+    else
+        hipLaunchKernelGGL(k_step64<false>, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI,
+                           ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,
+                           p->linearS2_bias, out);
+    GN_LAUNCH_CHECK();
+    return 0;
+}

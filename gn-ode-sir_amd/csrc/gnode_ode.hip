@@ -13,7 +13,9 @@
 // like the reference's separate torch ops; FMAs are written explicitly where
 // they are wanted (the generic node-MLP inner product).
 #include "gnode_common.h"
+#include "gnode_h64.h"
 #include <algorithm>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -36,6 +38,9 @@ struct ProfKind { std::vector<hipEvent_t> ev; size_t used = 0; };
 static bool g_prof_on = false;
 static ProfKind g_prof[2];   // 0 = gather/update kernel, 1 = node-MLP kernel
 
+static const int kProfEvery = 8;   // bracket one launch in 8: the events themselves cost GPU time
+static long g_prof_seq[2] = {0, 0};
+static bool prof_begin(int kind, hipStream_t st);
 static void prof_mark(int kind, hipStream_t st) {
     if (!g_prof_on) return;
     ProfKind& k = g_prof[kind];
@@ -47,7 +52,16 @@ static void prof_mark(int kind, hipStream_t st) {
     (void)hipEventRecord(k.ev[k.used++], st);
 }
 
+// begin(): returns true when this launch is sampled; the caller then calls prof_mark again after the launch
+static bool prof_begin(int kind, hipStream_t st) {
+    if (!g_prof_on) return false;
+    if ((g_prof_seq[kind]++ % kProfEvery) != 0) return false;
+    prof_mark(kind, st);
+    return true;
+}
+
 extern "C" int gnode_profile_enable(int on) {
+    g_prof_seq[0] = g_prof_seq[1] = 0;
     g_prof_on = on != 0;
     g_prof[0].used = g_prof[1].used = 0;
     return 0;
@@ -384,11 +398,9 @@ static int check_H(int H) {
 
 static int launch_mlp(const float* X, const float* W, const float* b, float* Z, long nrows, int H, hipStream_t st) {
     if (nrows == 0) return 0;
-    prof_mark(1, st);
+    const bool sampled = prof_begin(1, st);
     if (H == 64) {
-        long ntiles = (nrows + 31) / 32;
-        int grid = (int)std::min<long>((ntiles + 3) / 4, 256L * 8);
-        hipLaunchKernelGGL(k_mlp_mfma64, dim3(grid), dim3(256), 0, st, X, W, b, Z, nrows);
+        if (int e = gn_launch_mlp64(X, W, b, Z, nrows, st)) return e;
     } else {
         GN_CHECK_ARG(H <= 128, "generic node-MLP path supports H <= 128 (got %d)", H);
         const int lpr = lpr_for(H);
@@ -400,7 +412,7 @@ static int launch_mlp(const float* X, const float* W, const float* b, float* Z, 
             hipLaunchKernelGGL(k_mlp_generic<LPR>, dim3((unsigned)((nrows + rpw - 1) / rpw)), dim3(256), lds, st, X, W, b, Z, nrows, H);
         });
     }
-    prof_mark(1, st);
+    if (sampled) prof_mark(1, st);
     GN_LAUNCH_CHECK();
     return 0;
 }
@@ -414,7 +426,7 @@ static int launch_gather(gnode_graph_t g, int mode, long rows, int H, float* Y, 
     dim3 grid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)B);
     const float *w3 = p ? p->linear3_weight : nullptr, *b3 = p ? p->linear3_bias : nullptr;
     const float *w2 = p ? p->linearS2_weight : nullptr, *b2 = p ? p->linearS2_bias : nullptr;
-    prof_mark(0, st);
+    const bool sampled = mode == 1 && prof_begin(0, st);
     if (mode == 0) {
         DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_gather<LPR, 0>), grid, dim3(256), 0, st, g->rowptr, g->col, g->n, rows, H,
                                              Y, Z, beta, gamma, bg_stride, dt, dY, w3, b3, w2, b2, out));
@@ -422,7 +434,7 @@ static int launch_gather(gnode_graph_t g, int mode, long rows, int H, float* Y, 
         DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_gather<LPR, 1>), grid, dim3(256), 0, st, g->rowptr, g->col, g->n, rows, H,
                                              Y, Z, beta, gamma, bg_stride, dt, dY, w3, b3, w2, b2, out));
     }
-    prof_mark(0, st);
+    if (sampled) prof_mark(0, st);
     GN_LAUNCH_CHECK();
     return 0;
 }
@@ -573,11 +585,30 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         if (int e = launch_readout(Y, rows, H, p, S + (size_t)slot * rows, I + (size_t)slot * rows, R + (size_t)slot * rows, st))
             return e;
 
+    // H = 64: fused step kernels (gnode_h64.hip).  GNODE_FUSE=0 keeps Z_I in its own node-MLP launch.
+    const bool h64 = (H == 64 && method == 0);
+    static const bool fuse_zi = [] { const char* e = getenv("GNODE_FUSE"); return !(e && e[0] == '0'); }();
+    float* zi_cur = Z;
+    float* zi_nxt = Z + slab;
+    if (h64 && n_steps > 0)
+        if (int e = launch_mlp(Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
+
     for (int k = 0; k < n_steps; ++k) {
         const float dt = dt_host[k];
         slot = out_slot(k + 1);
         float* sol_next = sol ? sol + (size_t)(k + 1) * 4 * slab : nullptr;
-        if (method == 0) {
+        if (h64) {
+            Step64Out out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
+                             slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
+            const bool sampled = prof_begin(0, st);
+            if (int e = gn_launch_step64(g, rows, Y, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,
+                                         gamma, dt, p, out, fuse_zi, st))
+                return e;
+            if (sampled) prof_mark(0, st);
+            if (fuse_zi) std::swap(zi_cur, zi_nxt);
+            else if (k + 1 < n_steps)
+                if (int e = launch_mlp(Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
+        } else if (method == 0) {
             if (int e = launch_mlp(Y, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
             StepOut out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
                            slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
