@@ -134,6 +134,18 @@ def main():
     alg_bytes = algorithmic_bytes_per_sample_step(n, nnz, H) * chunk
     achieved = alg_bytes / gather_avg_s / 1e9 if gather_avg_s > 0 else 0.0
 
+    # HBM-side traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside
+    # this process): profiles/*pmc_step64.json, collected with this command line and corrected as
+    # MI355X_MICROARCH.md prescribes; only reported when the workload matches.
+    traffic = None
+    try:
+        import glob
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_step64.json")))
+        if pm and (n, nnz, H, chunk) == (75000, 1000000, 64, 8):
+            traffic = float(json.load(open(pm[-1]))["traffic_bytes_per_launch"])
+    except Exception:
+        traffic = None
+
     result = {
         "metric": "node-timesteps/sec (N*T/s) GN-ODE fwd, 75k-node graph, hidden=64",
         "value": value, "unit": "node-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -147,7 +159,7 @@ def main():
         "node_maxTime_per_s": world * B * n * args.maxTime * args.steps / elapsed,
         "roofline": {"bound": "hbm", "kernel": "k_step64<true> (CSR pull-gather + MFMA node MLP + SIR update + read-out, one launch per Euler step)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "avg_launch_us": gather_avg_s * 1e6, "launches": int(gcnt.value),
+                     "traffic": traffic, "avg_launch_us": gather_avg_s * 1e6, "launches": int(gcnt.value),
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "node_mlp_avg_launch_us": (mms.value / max(mcnt.value, 1)) * 1e3},
     }

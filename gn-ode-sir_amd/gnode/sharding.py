@@ -1,0 +1,76 @@
+"""Multi-GPU sharding of the path: independent units, one process per GPU.
+
+* forward / inference: (graph, beta, gamma, seed-set) samples are split into contiguous
+  per-rank blocks; the graph CSR is replicated; NO data-path collective (results are
+  gathered by the caller only if it wants them in one place).
+* Monte-Carlo labels: the `sims` range is split; coins are keyed by the GLOBAL sim
+  index, so the summed counts equal the single-GPU counts bit for bit.  One
+  all-reduce(sum) of the uint32 [3,T,n] counts per sample (RCCL over xGMI on GPUs).
+* training: local backward, one flat all-reduce of the 4 809-float gradient.
+Pure host logic + torch.distributed; works with the gloo backend on CPU tensors (tests)
+and with nccl (= RCCL) on GPU tensors.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous [lo, hi) block of `total` units for `rank`; sizes differ by at most one."""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def allreduce_counts(counts: torch.Tensor) -> torch.Tensor:
+    """Sum Monte-Carlo count shards [3,T,n] over ranks.  Row 0 of S and I is ASSIGNED by
+    every shard (reference quirk, ode_nn.py:55-56), so it is restored after the sum."""
+    rank, world = world_info()
+    if world == 1:
+        return counts
+    row0 = counts[:, 0].clone()
+    work = counts.to(torch.int64) if counts.dtype == torch.int32 and not counts.is_cuda else counts
+    dist.all_reduce(work, op=dist.ReduceOp.SUM)
+    if work is not counts:
+        counts.copy_(work.to(counts.dtype))
+    counts[:, 0] = row0
+    return counts
+
+
+def allreduce_flat_grads(params, scale: float = 1.0):
+    """One flat-buffer all-reduce(sum) of every parameter gradient (19 KB for H=64), then
+    scale (e.g. 1/global element count to keep the reference's element-mean L1 semantics,
+    ode_nn_ngraph_sim.py:248-249)."""
+    rank, world = world_info()
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if scale != 1.0:
+        flat.mul_(scale)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def gather_rows(local: torch.Tensor, sizes):
+    """all_gather of per-rank row blocks of unequal size along dim 1 ([G, rows_r] each)."""
+    rank, world = world_info()
+    if world == 1:
+        return local
+    mx = max(sizes)
+    pad = torch.zeros(local.shape[0], mx, dtype=local.dtype, device=local.device)
+    pad[:, :local.shape[1]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:, :s] for b, s in zip(bufs, sizes)], dim=1)
