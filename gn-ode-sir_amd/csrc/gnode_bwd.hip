@@ -1,0 +1,444 @@
+// Adjoint backward of the GN-ODE path for MI355X (gfx950).
+//
+// Semantics: torchdiffeq 0.2.2 `odeint_adjoint(..., method='euler')` as the reference
+// calls it (ode_nn_ngraph_sim.py:16,168).  With sol saved by the
+// forward and a = dL/dsol accumulated backwards,
+//     for i = G-1 .. 1:   u = a
+//         Z = sigmoid(W y_i + b) (S and I slabs), AI = A Z_I
+//         v  = beta (u_I - u_S)
+//         dZ_S = v * AI                  dZ_I = A^T (v * Z_S) + gamma (u_R - u_I)      (A symmetric)
+//         dpre = dZ * Z (1 - Z)
+//         a_{S,I} += dt_i * dpre W       gW += dt_i * dpre^T y_i      gb += dt_i * sum_rows dpre
+//         a += dL/dsol[i-1]                                            (head backward at grid point i-1)
+//     encoder backward on a_0.
+// The Jacobians are evaluated at the RIGHT endpoint y_i (one Euler step of the augmented
+// system from t_i to t_{i-1}), which is what the reference's training gradients are.
+//
+// Parameter gradients are reduced deterministically: every workgroup owns one slot of a
+// partial buffer [NWG][NP] that it updates with plain read-modify-writes across all
+// launches (fixed grid, fixed row->workgroup map); one final kernel sums the slots in
+// order.  No float atomics, bitwise reproducible run to run.
+#include "gnode_common.h"
+#include <algorithm>
+
+#define BWD_NWG 512
+
+__device__ __forceinline__ float4 ld4b(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4b(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 z4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+
+template <int LPR>
+__device__ __forceinline__ float gsum(float v) {
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, LPR);
+    return v;
+}
+
+// partial-buffer layout per workgroup (floats)
+struct PartLayout {
+    int H;
+    __host__ __device__ int oW() const { return 0; }
+    __host__ __device__ int ob() const { return H * H; }
+    __host__ __device__ int ow3() const { return H * H + H; }
+    __host__ __device__ int ob3() const { return H * H + 5 * H; }
+    __host__ __device__ int ow2() const { return H * H + 5 * H + 4; }
+    __host__ __device__ int ob2() const { return H * H + 5 * H + 8; }
+    __host__ __device__ int ow1() const { return H * H + 5 * H + 9; }
+    __host__ __device__ int ob1() const { return H * H + 6 * H + 9; }
+    __host__ __device__ int total() const { return H * H + 7 * H + 9; }
+};
+
+// Deterministic in-workgroup reduction of per-group contributions staged in LDS:
+// red[group][NE] -> part[e] += sum_groups (fixed order).
+__device__ __forceinline__ void flush_groups(const float* red, int ngroups, int ne, float* __restrict__ part) {
+    for (int e = threadIdx.x; e < ne; e += 256) {
+        float s = 0.f;
+        for (int gidx = 0; gidx < ngroups; ++gidx) s += red[(size_t)gidx * ne + e];
+        part[e] += s;
+    }
+}
+
+// --------------------------------------------------------------------------- head backward at one grid point
+// a[3][rows][H] += d(readout+softmax)/dY ; partial grads of linear3 / linearS2.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ Ysol, long rows, int H,
+                                                  const float* __restrict__ gS, const float* __restrict__ gI,
+                                                  const float* __restrict__ gR, const float* __restrict__ w3,
+                                                  const float* __restrict__ b3, const float* __restrict__ w2,
+                                                  const float* __restrict__ b2, float* __restrict__ a,
+                                                  float* __restrict__ part_all) {
+    extern __shared__ float red[];                       // [G][4H + 9]
+    constexpr int G = 256 / LPR;
+    const PartLayout L{H};
+    const int ne = 4 * H + 9;
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const bool active = 4 * sub < H;
+    const size_t slab = (size_t)rows * H;
+    float4 w3v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w3v[k] = active ? ld4b(w3 + (size_t)k * H + 4 * sub) : z4();
+    float4 dw3[4] = {z4(), z4(), z4(), z4()};
+    float db3[4] = {0.f, 0.f, 0.f, 0.f}, dw2[4] = {0.f, 0.f, 0.f, 0.f}, db2 = 0.f;
+    for (long r = (long)blockIdx.x * G + grp; r < rows; r += (long)gridDim.x * G) {
+        const size_t off = (size_t)r * H + 4 * sub;
+        float4 y[3];
+#pragma unroll
+        for (int X = 0; X < 3; ++X) y[X] = active ? ld4b(Ysol + X * slab + off) : z4();
+        float p3[3][4], q[3];
+#pragma unroll
+        for (int X = 0; X < 3; ++X) {
+            q[X] = b2[0];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                p3[X][k] = gsum<LPR>(dot4(w3v[k], y[X])) + b3[k];
+                q[X] = fmaf(w2[k], fmaxf(p3[X][k], 0.f), q[X]);
+            }
+        }
+        const float m = fmaxf(q[0], fmaxf(q[1], q[2]));
+        float e0 = __expf(q[0] - m), e1 = __expf(q[1] - m), e2 = __expf(q[2] - m);
+        const float inv = 1.0f / (e0 + e1 + e2);
+        const float p[3] = {e0 * inv, e1 * inv, e2 * inv};
+        const float g[3] = {gS[r], gI[r], gR[r]};
+        const float gp = g[0] * p[0] + g[1] * p[1] + g[2] * p[2];
+#pragma unroll
+        for (int X = 0; X < 3; ++X) {
+            const float dq = p[X] * (g[X] - gp);
+            float4 dy = z4();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dp3 = p3[X][k] > 0.f ? dq * w2[k] : 0.f;
+                dy.x = fmaf(dp3, w3v[k].x, dy.x); dy.y = fmaf(dp3, w3v[k].y, dy.y);
+                dy.z = fmaf(dp3, w3v[k].z, dy.z); dy.w = fmaf(dp3, w3v[k].w, dy.w);
+                dw3[k].x = fmaf(dp3, y[X].x, dw3[k].x); dw3[k].y = fmaf(dp3, y[X].y, dw3[k].y);
+                dw3[k].z = fmaf(dp3, y[X].z, dw3[k].z); dw3[k].w = fmaf(dp3, y[X].w, dw3[k].w);
+                db3[k] += dp3;
+                dw2[k] = fmaf(dq, fmaxf(p3[X][k], 0.f), dw2[k]);
+            }
+            db2 += dq;
+            if (active) {
+                float4 av = ld4b(a + X * slab + off);
+                av.x += dy.x; av.y += dy.y; av.z += dy.z; av.w += dy.w;
+                st4b(a + X * slab + off, av);
+            }
+        }
+    }
+    float* mine = red + (size_t)grp * ne;
+    if (active)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st4b(mine + k * H + 4 * sub, dw3[k]);
+    if (sub == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { mine[4 * H + k] = db3[k]; mine[4 * H + 4 + k] = dw2[k]; }
+        mine[4 * H + 8] = db2;
+    }
+    __syncthreads();
+    flush_groups(red, G, ne, part_all + (size_t)blockIdx.x * L.total() + L.ow3());
+}
+
+// --------------------------------------------------------------------------- q = beta (a_I - a_S) * Z_S
+__global__ __launch_bounds__(256) void k_bwd_q(const float* __restrict__ a, const float* __restrict__ ZS,
+                                               const float* __restrict__ beta, float* __restrict__ q, long rows, int H) {
+    const size_t slab = (size_t)rows * H, n4 = slab / 4;
+    const int h4 = H / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float bt = beta[i / h4];
+        const float4 aS = ld4b(a + 4 * i), aI = ld4b(a + slab + 4 * i), z = ld4b(ZS + 4 * i);
+        st4b(q + 4 * i, make_float4(bt * (aI.x - aS.x) * z.x, bt * (aI.y - aS.y) * z.y, bt * (aI.z - aS.z) * z.z,
+                                    bt * (aI.w - aS.w) * z.w));
+    }
+}
+
+// --------------------------------------------------------------------------- gathers + dpre
+template <int LPR>
+__global__ __launch_bounds__(256) void k_bwd_gather(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+                                                    long rows, int H, const float* __restrict__ a,
+                                                    const float* __restrict__ Z, const float* __restrict__ q,
+                                                    const float* __restrict__ beta, const float* __restrict__ gamma,
+                                                    float* __restrict__ dpre) {
+    const int sub = threadIdx.x % LPR;
+    const int node = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (node >= n) return;
+    const bool active = 4 * sub < H;
+    const long base = (long)blockIdx.y * n, r = base + node;
+    const size_t slab = (size_t)rows * H, off = (size_t)r * H + 4 * sub;
+    const float* ZI = Z + slab;
+    float4 ai = z4(), gq = z4();
+    const int start = rowptr[node], end = rowptr[node + 1];
+    for (int e0 = start; e0 < end; e0 += LPR) {
+        const int cnt = min(LPR, end - e0);
+        const int mine = (sub < cnt) ? col[e0 + sub] : 0;
+        for (int j = 0; j < cnt; ++j) {
+            const int c = __shfl(mine, j, LPR);
+            if (active) {
+                const float4 v = ld4b(ZI + (size_t)(base + c) * H + 4 * sub);
+                const float4 u = ld4b(q + (size_t)(base + c) * H + 4 * sub);
+                ai.x += v.x; ai.y += v.y; ai.z += v.z; ai.w += v.w;
+                gq.x += u.x; gq.y += u.y; gq.z += u.z; gq.w += u.w;
+            }
+        }
+    }
+    if (!active) return;
+    const float bt = beta[r], gm = gamma[r];
+    const float4 aS = ld4b(a + off), aI = ld4b(a + slab + off), aR = ld4b(a + 2 * slab + off);
+    const float4 zs = ld4b(Z + off), zi = ld4b(ZI + off);
+    float4 dS, dI;
+#define GN_DPRE(c)                                                         \
+    {                                                                      \
+        const float v = bt * (aI.c - aS.c);                                \
+        dS.c = (v * ai.c) * (zs.c * (1.0f - zs.c));                        \
+        dI.c = (gq.c + gm * (aR.c - aI.c)) * (zi.c * (1.0f - zi.c));       \
+    }
+    GN_DPRE(x) GN_DPRE(y) GN_DPRE(z) GN_DPRE(w)
+#undef GN_DPRE
+    st4b(dpre + off, dS);
+    st4b(dpre + slab + off, dI);
+}
+
+// --------------------------------------------------------------------------- a += dt dpre W ; partial gW, gb
+template <int LPR>
+__global__ __launch_bounds__(256) void k_bwd_mlp(const float* __restrict__ dpre, const float* __restrict__ Ysol,
+                                                 const float* __restrict__ W, float dt, float* __restrict__ a, long rows,
+                                                 int H, float* __restrict__ part_all) {
+    extern __shared__ float lds[];
+    constexpr int G = 256 / LPR;
+    const PartLayout L{H};
+    float* Wl = lds;                           // [H][H]   W[j][k]
+    float* Dt = Wl + (size_t)H * H;            // [2][G][H] dpre tile (S, I)
+    float* Yt = Dt + (size_t)2 * G * H;        // [2][G][H] y tile   (S, I)
+    for (int idx = threadIdx.x; idx < H * H; idx += 256) Wl[idx] = W[idx];
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const bool lane_ok = 4 * sub < H;
+    const size_t slab = (size_t)rows * H;
+    const int nE = H * H;
+    constexpr int MAXM = 64;                   // entries of gW per thread: H*H/256 <= 64 for H <= 128
+    float accW[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) accW[m] = 0.f;
+    float accb = 0.f;
+    const int M = (nE + 255) / 256;
+    for (long r0 = (long)blockIdx.x * G; r0 < rows; r0 += (long)gridDim.x * G) {
+        const long r = r0 + grp;
+        const bool ok = lane_ok && r < rows;
+        const size_t off = (size_t)r * H + 4 * sub;
+        __syncthreads();                       // previous tile fully consumed (also covers the W stage)
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            st4b(Dt + ((size_t)X * G + grp) * H + 4 * sub, ok ? ld4b(dpre + X * slab + off) : z4());
+            st4b(Yt + ((size_t)X * G + grp) * H + 4 * sub, ok ? ld4b(Ysol + X * slab + off) : z4());
+        }
+        __syncthreads();
+        // g_Y = dpre W  (this lane: 4 columns of its own row, both slabs)
+        float4 gS = z4(), gI = z4();
+        const float* dS = Dt + (size_t)grp * H;
+        const float* dI = Dt + ((size_t)G + grp) * H;
+        for (int j = 0; j < H; ++j) {
+            const float4 w = lane_ok ? ld4b(Wl + (size_t)j * H + 4 * sub) : z4();
+            const float s = dS[j], i = dI[j];
+            gS.x = fmaf(s, w.x, gS.x); gS.y = fmaf(s, w.y, gS.y); gS.z = fmaf(s, w.z, gS.z); gS.w = fmaf(s, w.w, gS.w);
+            gI.x = fmaf(i, w.x, gI.x); gI.y = fmaf(i, w.y, gI.y); gI.z = fmaf(i, w.z, gI.z); gI.w = fmaf(i, w.w, gI.w);
+        }
+        if (ok) {
+            float4 aS = ld4b(a + off), aI = ld4b(a + slab + off);
+            aS.x += dt * gS.x; aS.y += dt * gS.y; aS.z += dt * gS.z; aS.w += dt * gS.w;
+            aI.x += dt * gI.x; aI.y += dt * gI.y; aI.z += dt * gI.z; aI.w += dt * gI.w;
+            st4b(a + off, aS); st4b(a + slab + off, aI);
+        }
+        // gW[j][k] += sum_rows dpre[r][j] * y[r][k]   (thread owns entries e = tid + 256 m)
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) {
+            if (m < M) {
+                const int e = threadIdx.x + 256 * m;
+                if (e < nE) {
+                    const int j = e / H, k = e % H;
+                    float s = 0.f;
+                    for (int rr = 0; rr < 2 * G; ++rr) s = fmaf(Dt[(size_t)rr * H + j], Yt[(size_t)rr * H + k], s);
+                    accW[m] += s;
+                }
+            }
+        }
+        if (threadIdx.x < H) {
+            float s = 0.f;
+            for (int rr = 0; rr < 2 * G; ++rr) s += Dt[(size_t)rr * H + threadIdx.x];
+            accb += s;
+        }
+    }
+    float* part = part_all + (size_t)blockIdx.x * L.total();
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+        if (m < M) {
+            const int e = threadIdx.x + 256 * m;
+            if (e < nE) part[L.oW() + e] += dt * accW[m];
+        }
+    }
+    if (threadIdx.x < H) part[L.ob() + threadIdx.x] += dt * accb;
+}
+
+// --------------------------------------------------------------------------- encoder backward
+template <int LPR>
+__global__ __launch_bounds__(256) void k_enc_bwd(const float* __restrict__ a, const float* __restrict__ sol0,
+                                                 const float* __restrict__ x, long rows, int H,
+                                                 float* __restrict__ part_all) {
+    extern __shared__ float red[];                       // [G][2H]
+    constexpr int G = 256 / LPR;
+    const PartLayout L{H};
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const bool active = 4 * sub < H;
+    const size_t slab = (size_t)rows * H;
+    float4 dw = z4(), db = z4();
+    for (long r = (long)blockIdx.x * G + grp; r < rows; r += (long)gridDim.x * G) {
+        if (!active) continue;
+        const size_t off = (size_t)r * H + 4 * sub;
+#pragma unroll
+        for (int X = 0; X < 3; ++X) {
+            const float s = x[(size_t)r * (3 + H) + X];
+            const float4 y = ld4b(sol0 + X * slab + off), av = ld4b(a + X * slab + off);
+            const float4 mk = make_float4(y.x > 0.f ? av.x : 0.f, y.y > 0.f ? av.y : 0.f, y.z > 0.f ? av.z : 0.f,
+                                          y.w > 0.f ? av.w : 0.f);
+            dw.x = fmaf(mk.x, s, dw.x); dw.y = fmaf(mk.y, s, dw.y); dw.z = fmaf(mk.z, s, dw.z); dw.w = fmaf(mk.w, s, dw.w);
+            db.x += mk.x; db.y += mk.y; db.z += mk.z; db.w += mk.w;
+        }
+    }
+    float* mine = red + (size_t)grp * 2 * H;
+    if (active) { st4b(mine + 4 * sub, dw); st4b(mine + H + 4 * sub, db); }
+    __syncthreads();
+    flush_groups(red, G, 2 * H, part_all + (size_t)blockIdx.x * L.total() + L.ow1());
+}
+
+__global__ __launch_bounds__(256) void k_reduce_parts(const float* __restrict__ part_all, int nwg, int total,
+                                                      float* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float s = 0.f;
+    for (int w = 0; w < nwg; ++w) s += part_all[(size_t)w * total + e];
+    out[e] = s;
+}
+
+// --------------------------------------------------------------------------- host
+int gn_launch_mlp_any(const float* X, const float* W, const float* b, float* Z, long nrows, int H, hipStream_t st);
+
+static int lpr_of(int H) {
+    int need = H / 4, l = 1;
+    while (l < need) l <<= 1;
+    return l;
+}
+
+#define BWD_DISPATCH(lpr, ...)                                   \
+    switch (lpr) {                                               \
+        case 1: { constexpr int LPR = 1; __VA_ARGS__; } break;   \
+        case 2: { constexpr int LPR = 2; __VA_ARGS__; } break;   \
+        case 4: { constexpr int LPR = 4; __VA_ARGS__; } break;   \
+        case 8: { constexpr int LPR = 8; __VA_ARGS__; } break;   \
+        case 16: { constexpr int LPR = 16; __VA_ARGS__; } break; \
+        default: { constexpr int LPR = 32; __VA_ARGS__; } break; \
+    }
+
+__global__ void k_extract_bg(const float* __restrict__ bgslab, long rows, int H, float* __restrict__ beta,
+                             float* __restrict__ gamma) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    beta[r] = bgslab[(size_t)r * H];
+    gamma[r] = bgslab[(size_t)r * H + 1];
+}
+
+extern "C" size_t gnode_backward_workspace_bytes(int64_t rows, int32_t H) {
+    const PartLayout L{H};
+    const size_t slab = gn_align((size_t)rows * H * sizeof(float));
+    // a[3], Z[2], q[1], dpre[2] slabs + beta, gamma + partial buffer + reduced gradient vector
+    return 8 * slab + 2 * gn_align((size_t)rows * sizeof(float)) +
+           gn_align((size_t)BWD_NWG * L.total() * sizeof(float)) + gn_align((size_t)L.total() * sizeof(float));
+}
+
+extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
+                                  int32_t n_steps, const int32_t* out_rows_host, int32_t n_out, const float* sol,
+                                  const float* gS, const float* gI, const float* gR, const gnode_params* grads,
+                                  int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream) {
+    GN_CHECK_ARG(g && x && p && sol && gS && gI && gR && grads && workspace, "gnode_backward_f32: null pointer");
+    GN_CHECK_ARG(n_steps >= 0 && (n_steps == 0 || dt_host), "gnode_backward_f32: bad n_steps/dt");
+    GN_CHECK_ARG(H >= 4 && H <= 128 && H % 4 == 0, "gnode_backward_f32: need 4 <= H <= 128, H %% 4 == 0 (got %d)", H);
+    GN_CHECK_ARG(rows > 0 && rows % g->n == 0, "gnode_backward_f32: rows=%lld is not a multiple of graph n=%d",
+                 (long long)rows, g->n);
+    GN_CHECK_ARG(grads->odefunc_linear_weight && grads->odefunc_linear_bias && grads->linearS1_weight &&
+                     grads->linearS1_bias && grads->linear3_weight && grads->linear3_bias && grads->linearS2_weight &&
+                     grads->linearS2_bias, "gnode_backward_f32: null gradient pointer");
+    if (workspace_bytes < gnode_backward_workspace_bytes(rows, H)) {
+        gnode_set_error("gnode_backward_f32: workspace %zu < %zu", workspace_bytes, gnode_backward_workspace_bytes(rows, H));
+        return GNODE_ERR_WORKSPACE;
+    }
+    const int G = n_steps + 1;
+    if (out_rows_host)
+        for (int i = 0; i < n_out; ++i)
+            GN_CHECK_ARG(out_rows_host[i] >= 0 && out_rows_host[i] < G && (i == 0 || out_rows_host[i] > out_rows_host[i - 1]),
+                         "gnode_backward_f32: out_rows must be ascending grid indices in [0,%d)", G);
+    hipStream_t st = (hipStream_t)stream;
+    const PartLayout L{H};
+    const size_t slab = (size_t)rows * H, slab_b = gn_align(slab * sizeof(float));
+    const size_t vec_b = gn_align((size_t)rows * sizeof(float));
+    char* ws = (char*)workspace;
+    float* a = (float*)ws;                               // 3 slabs (element-contiguous inside 3 aligned slabs)
+    float* Z = (float*)(ws + 3 * slab_b);                // 2 slabs
+    float* q = (float*)(ws + 5 * slab_b);                // 1 slab
+    float* dpre = (float*)(ws + 6 * slab_b);             // 2 slabs
+    float* beta = (float*)(ws + 8 * slab_b);
+    float* gamma = (float*)(ws + 8 * slab_b + vec_b);
+    float* part = (float*)(ws + 8 * slab_b + 2 * vec_b);
+    float* red = (float*)(ws + 8 * slab_b + 2 * vec_b + gn_align((size_t)BWD_NWG * L.total() * sizeof(float)));
+    GN_HIP(hipMemsetAsync(a, 0, 3 * slab * sizeof(float), st));
+    GN_HIP(hipMemsetAsync(part, 0, (size_t)BWD_NWG * L.total() * sizeof(float), st));
+    hipLaunchKernelGGL(k_extract_bg, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, sol + 3 * slab, (long)rows, H,
+                       beta, gamma);
+    GN_LAUNCH_CHECK();
+
+    const int lpr = lpr_of(H), rpw = 256 / lpr;
+    auto slot_of = [&](int gi) -> int {
+        if (!out_rows_host) return gi;
+        for (int i = 0; i < n_out; ++i) if (out_rows_host[i] == gi) return i;
+        return -1;
+    };
+    auto head = [&](int gi) -> int {
+        const int s = slot_of(gi);
+        if (s < 0) return 0;
+        const size_t lds = (size_t)rpw * (4 * H + 9) * sizeof(float);
+        BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_head_bwd<LPR>, dim3(BWD_NWG), dim3(256), lds, st, sol + (size_t)gi * 4 * slab,
+                                             (long)rows, H, gS + (size_t)s * rows, gI + (size_t)s * rows, gR + (size_t)s * rows,
+                                             p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, a, part));
+        GN_LAUNCH_CHECK();
+        return 0;
+    };
+    if (int e = head(G - 1)) return e;
+    const size_t mlp_lds = ((size_t)H * H + (size_t)4 * rpw * H) * sizeof(float);
+    for (int i = G - 1; i >= 1; --i) {
+        const float* yi = sol + (size_t)i * 4 * slab;
+        const float dt = dt_host[i - 1];
+        if (int e = gn_launch_mlp_any(yi, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
+        hipLaunchKernelGGL(k_bwd_q, dim3(2048), dim3(256), 0, st, a, Z, beta, q, (long)rows, H);
+        GN_LAUNCH_CHECK();
+        dim3 ggrid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)(rows / g->n));
+        BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_bwd_gather<LPR>, ggrid, dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, H, a,
+                                             Z, q, beta, gamma, dpre));
+        GN_LAUNCH_CHECK();
+        BWD_DISPATCH(lpr, {
+            if (mlp_lds > 64 * 1024)
+                GN_HIP(hipFuncSetAttribute((const void*)k_bwd_mlp<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds));
+            hipLaunchKernelGGL(k_bwd_mlp<LPR>, dim3(BWD_NWG), dim3(256), mlp_lds, st, dpre, yi, p->odefunc_linear_weight, dt, a,
+                               (long)rows, H, part);
+        });
+        GN_LAUNCH_CHECK();
+        if (int e = head(i - 1)) return e;
+    }
+    {
+        const size_t lds = (size_t)rpw * 2 * H * sizeof(float);
+        BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_enc_bwd<LPR>, dim3(BWD_NWG), dim3(256), lds, st, a, sol, x, (long)rows, H, part));
+        GN_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_reduce_parts, dim3((L.total() + 255) / 256), dim3(256), 0, st, part, BWD_NWG, L.total(), red);
+    GN_LAUNCH_CHECK();
+    struct { float* dst; int off; int cnt; } outv[] = {
+        {(float*)grads->odefunc_linear_weight, L.oW(), H * H}, {(float*)grads->odefunc_linear_bias, L.ob(), H},
+        {(float*)grads->linear3_weight, L.ow3(), 4 * H},       {(float*)grads->linear3_bias, L.ob3(), 4},
+        {(float*)grads->linearS2_weight, L.ow2(), 4},          {(float*)grads->linearS2_bias, L.ob2(), 1},
+        {(float*)grads->linearS1_weight, L.ow1(), H},          {(float*)grads->linearS1_bias, L.ob1(), H}};
+    for (auto& o : outv)
+        GN_HIP(hipMemcpyAsync(o.dst, red + o.off, sizeof(float) * o.cnt, hipMemcpyDeviceToDevice, st));
+    return 0;
+}

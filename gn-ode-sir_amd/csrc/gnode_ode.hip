@@ -417,6 +417,10 @@ static int launch_mlp(const float* X, const float* W, const float* b, float* Z, 
     return 0;
 }
 
+int gn_launch_mlp_any(const float* X, const float* W, const float* b, float* Z, long nrows, int H, hipStream_t st) {
+    return launch_mlp(X, W, b, Z, nrows, H, st);
+}
+
 // dY or in-place Euler update from (Y, Z)
 static int launch_gather(gnode_graph_t g, int mode, long rows, int H, float* Y, const float* Z, const float* beta,
                          const float* gamma, int bg_stride, float dt, float* dY, const gnode_params* p, StepOut out,

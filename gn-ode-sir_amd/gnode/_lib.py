@@ -18,6 +18,7 @@ EXPORTS = [
     "gnode_graph_create", "gnode_graph_destroy", "gnode_graph_info",
     "gnode_rhs_workspace_bytes", "gnode_rhs_f32",
     "gnode_forward_workspace_bytes", "gnode_forward_f32",
+    "gnode_backward_workspace_bytes", "gnode_backward_f32",
     "gnode_sir_workspace_bytes", "gnode_sir_coins_workspace_bytes",
     "gnode_sir_mc_philox", "gnode_sir_mc_coins",
     "gnode_profile_enable", "gnode_profile_read",
@@ -64,11 +65,11 @@ def load():
     lib.gnode_forward_workspace_bytes.argtypes = [i64, i32, i32]
     lib.gnode_forward_workspace_bytes.restype = sz
     lib.gnode_forward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp, sz, vp]
-    if hasattr(lib, "gnode_backward_f32"):
-        lib.gnode_backward_workspace_bytes.argtypes = [i64, i32]
-        lib.gnode_backward_workspace_bytes.restype = sz
-        lib.gnode_backward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, vp, i32, vp, vp, vp, vp,
-                                           C.POINTER(Grads), vp, i64, i32, vp, sz, vp]
+    lib.gnode_backward_workspace_bytes.argtypes = [i64, i32]
+    lib.gnode_backward_workspace_bytes.restype = sz
+    lib.gnode_backward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, vp, i32, vp, vp, vp, vp,
+                                       C.POINTER(Params), i64, i32, vp, sz, vp]
+    lib.gnode_backward_f32.restype = C.c_int
     lib.gnode_sir_workspace_bytes.argtypes = [vp, i32]
     lib.gnode_sir_workspace_bytes.restype = sz
     lib.gnode_sir_coins_workspace_bytes.restype = sz

@@ -92,3 +92,33 @@ def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray
         _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(sol) if sol is not None else None,
         rows, H, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
     return out[0], out[1], out[2], sol
+
+
+def backward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray, method: str, out_rows, sol: torch.Tensor,
+             gS: torch.Tensor, gI: torch.Tensor, gR: torch.Tensor) -> dict:
+    """Adjoint-Euler parameter gradients (torchdiffeq odeint_adjoint semantics)
+    given the saved trajectory `sol` and the upstream gradients of S, I, R ([n_out, rows])."""
+    if method != "euler":
+        raise _lib.GnodeError("the adjoint backward is implemented for method='euler' (the reference's method)")
+    lib = _lib.load()
+    x2d = _f32c(x2d)
+    rows, H = x2d.shape[0], x2d.shape[1] - 3
+    dts = np.ascontiguousarray(dts, dtype=np.float32)
+    n_steps = int(dts.shape[0])
+    if out_rows is not None:
+        out_rows = np.ascontiguousarray(out_rows, dtype=np.int32)
+        n_out = int(out_rows.shape[0])
+    else:
+        n_out = n_steps + 1
+    for t in (gS, gI, gR):
+        if tuple(t.shape) != (n_out, rows):
+            raise _lib.GnodeError(f"upstream gradient shape {tuple(t.shape)} != {(n_out, rows)}")
+    grads = {k: torch.empty_like(params[k], memory_format=torch.contiguous_format) for k in PARAM_KEYS}
+    ws = _workspace(lib.gnode_backward_workspace_bytes(rows, H), x2d.device)
+    p, gp = pack_params({k: v.detach() for k, v in params.items()}), pack_params(grads)
+    _lib.check(lib.gnode_backward_f32(
+        graph.handle, _lib.ptr(x2d), C.byref(p), _lib.host_ptr(dts), n_steps,
+        _lib.host_ptr(out_rows) if out_rows is not None else None, n_out, _lib.ptr(_f32c(sol)),
+        _lib.ptr(_f32c(gS)), _lib.ptr(_f32c(gI)), _lib.ptr(_f32c(gR)), C.byref(gp), rows, H,
+        _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    return grads

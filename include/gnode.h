@@ -97,6 +97,21 @@ int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, co
                       float* S, float* I, float* R, float* sol, int64_t rows, int32_t H,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- backward -------------------------------------------------------------
+ * The gradient the reference trains with: torchdiffeq's odeint_adjoint under
+ * method='euler' (imported at ode_nn_ngraph_sim.py:16, called at :168; semantics in
+ * SURVEY Appendix A) followed by autograd through the head and the encoder.
+ *   sol          device [n_steps+1, 4*rows, H] saved by gnode_forward_f32
+ *   gS, gI, gR   device [n_out, rows] upstream gradients of the outputs
+ *   grads        device pointers (same struct as the parameters) that RECEIVE
+ *                dL/dparam (overwritten, not accumulated)
+ * Euler only (the reference's method).  Deterministic (no float atomics). */
+size_t gnode_backward_workspace_bytes(int64_t rows, int32_t H);
+int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
+                       int32_t n_steps, const int32_t* out_rows_host, int32_t n_out, const float* sol,
+                       const float* gS, const float* gI, const float* gR, const gnode_params* grads,
+                       int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- Monte-Carlo SIR labels ------------------------------------------------
  * sir_torch(G, seed_set, beta, gamma, sims, T): ode_nn.py:30-88.
  *

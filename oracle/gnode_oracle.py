@@ -466,3 +466,78 @@ def make_samples(n, B, H, seed=0, n_seeds=2):
         x[b, :, 3] = rng.uniform(0.1, 0.5)
         x[b, :, 4] = rng.uniform(0.1, 0.5)
     return x
+
+
+# --------------------------------------------------------------------------- adjoint backward (A7)
+def adjoint_grads_torch(x, P, rowptr, col, maxTime, deltaT, gS, gI, gR, out_rows=None, dtype="float32"):
+    """Parameter gradients of  L = <gS,S> + <gI,I> + <gR,R>  as torchdiffeq 0.2.2's
+    ``odeint_adjoint(..., method='euler')`` produces them -- PARITY
+    UNPINNED (third-party, absent); restated here with torch autograd supplying every
+    vector-Jacobian product, exactly like torchdiffeq's augmented dynamics do:
+
+      forward under no_grad, ``sol`` saved;  a <- dL/dsol[G-1];  for i = G-1 .. 1:
+          f = func(t_i, sol[i]);  (vjp_y, vjp_theta) = grad(f, (y, theta), a)
+          a <- a + dt_i * vjp_y + dL/dsol[i-1];   g_theta <- g_theta + dt_i * vjp_theta
+      (one Euler step of the augmented system from t_i to t_{i-1}: the Jacobians are taken
+      at the RIGHT endpoint y_i, then y is reset to the stored sol[i-1]);  a_0 flows into
+      the encoder.  The head (Linear(H,4), relu, Linear(4,1), softmax) is ordinary autograd
+      on ``sol``.   x [B,n,3+H]; gS,gI,gR [n_out, B*n].  Returns {state_dict key: grad}.
+    """
+    import torch
+    dt_t = getattr(torch, dtype)
+    tt = lambda a: torch.tensor(np.asarray(a), dtype=dt_t)
+    Pt = {k: tt(v).requires_grad_(True) for k, v in P.items()}
+    xt = tt(x)
+    B, n = xt.shape[0], xt.shape[1]
+    x2 = xt.reshape(-1, xt.shape[2])
+    rows = x2.shape[0]
+    src = torch.from_numpy(np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr)))
+    dst = torch.from_numpy(col.astype(np.int64))
+    ridx = torch.cat([src + b * n for b in range(B)])
+    cidx = torch.cat([dst + b * n for b in range(B)])
+
+    def func(y, W, b):
+        q = y.shape[0] // 4
+        Z = torch.sigmoid(torch.nn.functional.linear(y[:2 * q], W, b))
+        ZS, ZI = Z[:q], Z[q:]
+        beta, gamma = y[3 * q:, 0:1], y[3 * q:, 1:2]
+        AI = torch.zeros_like(ZI).index_add(0, ridx, ZI[cidx])
+        dS = -beta * (AI * ZS)
+        dI = -dS - gamma * ZI
+        dR = gamma * ZI
+        return torch.cat((dS, dI, dR, torch.zeros_like(y[3 * q:])))
+
+    enc = lambda v: torch.relu(torch.nn.functional.linear(v.unsqueeze(-1), Pt["linearS1.weight"], Pt["linearS1.bias"]))
+    y0 = torch.cat((enc(x2[:, 0]), enc(x2[:, 1]), enc(x2[:, 2]), x2[:, 3:]))
+    grid = time_grid(maxTime, deltaT)
+    dts = step_sizes(grid)
+    W, b = Pt["odefunc.linear.weight"], Pt["odefunc.linear.bias"]
+    with torch.no_grad():
+        sol = [y0.detach()]
+        for dt in dts:
+            sol.append(sol[-1] + float(dt) * func(sol[-1], W, b))
+        sol = torch.stack(sol)
+    sol_leaf = sol.clone().requires_grad_(True)
+    ro = lambda Y: torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(Y, Pt["linear3.weight"], Pt["linear3.bias"])),
+                                              Pt["linearS2.weight"], Pt["linearS2.bias"])
+    out = torch.softmax(torch.cat((ro(sol_leaf[:, :rows]), ro(sol_leaf[:, rows:2 * rows]), ro(sol_leaf[:, 2 * rows:3 * rows])), -1), dim=2)
+    idx = torch.arange(sol.shape[0]) if out_rows is None else torch.as_tensor(np.asarray(out_rows), dtype=torch.int64)
+    L = (out[idx, :, 0] * tt(gS)).sum() + (out[idx, :, 1] * tt(gI)).sum() + (out[idx, :, 2] * tt(gR)).sum()
+    head = ["linear3.weight", "linear3.bias", "linearS2.weight", "linearS2.bias"]
+    gr = torch.autograd.grad(L, [sol_leaf] + [Pt[k] for k in head])
+    gsol = gr[0]
+    grads = {k: g for k, g in zip(head, gr[1:])}
+    a = gsol[-1].clone()
+    gW, gb = torch.zeros_like(W), torch.zeros_like(b)
+    for i in range(sol.shape[0] - 1, 0, -1):
+        yi = sol[i].clone().requires_grad_(True)
+        f = func(yi, W, b)
+        vy, vW, vb = torch.autograd.grad(f, (yi, W, b), a)
+        dt = float(dts[i - 1])
+        a = a + dt * vy + gsol[i - 1]
+        gW += dt * vW
+        gb += dt * vb
+    grads["odefunc.linear.weight"], grads["odefunc.linear.bias"] = gW, gb
+    ge = torch.autograd.grad(y0, [Pt["linearS1.weight"], Pt["linearS1.bias"]], a)
+    grads["linearS1.weight"], grads["linearS1.bias"] = ge
+    return {k: v.detach().numpy() for k, v in grads.items()}
