@@ -66,11 +66,18 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the GN-ODE path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters for rehearsals with more ranks than GPUs on a dev box
+    # (GNODE_DIST_BACKEND=gloo there: RCCL refuses two ranks on one device)
+    local_dev = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    backend = os.environ.get("GNODE_DIST_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import gnode_oracle as O
     from gnode import _lib, ops
@@ -119,7 +126,7 @@ def main():
     lib.gnode_profile_read(C.byref(gms), C.byref(gcnt), C.byref(mms), C.byref(mcnt))
     lib.gnode_profile_enable(0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -32,6 +32,18 @@ __device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// streaming (read-once / write-once) accesses: keep them out of the way of the gather table in L2
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld4s(const float* p) {
+    if (NT) { const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return ld4g(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st4s(float* p, float4 v) {
+    if (NT) { v4f t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p)); }
+    else st4g(p, v);
+}
 
 // ---- DPP helpers: a 16-lane group is exactly one DPP row -----------------------------
 template <int CTRL>
@@ -184,7 +196,7 @@ __device__ __forceinline__ void readout64(float4 yS, float4 yI, float4 yR, int s
     pS = eS * inv; pI = eI * inv; pR = eR * inv;
 }
 
-template <bool FUSE>
+template <bool FUSE, bool NT>
 __global__ __launch_bounds__(256) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                 long rows, int tiles_per_sample, long total_tiles,
                                                 float* __restrict__ Y, const float* __restrict__ ZI,
@@ -215,14 +227,14 @@ __global__ __launch_bounds__(256) void k_step64(const int* __restrict__ rowptr, 
             node[p] = tile * TILE_ROWS + lr[p];
             valid[p] = node[p] < n;
             off[p] = (size_t)(base + node[p]) * 64 + 4 * sub;
-            ys[p] = valid[p] ? ld4g(YS + off[p]) : zero4();
+            ys[p] = valid[p] ? ld4s<NT>(YS + off[p]) : zero4();
         }
         // -------- P1: stage Y_S, issue own-row loads, gather
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             *reinterpret_cast<float4*>(T + lr[p] * TS + 4 * sub) = ys[p];
-            yi[p] = valid[p] ? ld4g(YI + off[p]) : zero4();
-            yr[p] = valid[p] ? ld4g(YR + off[p]) : zero4();
+            yi[p] = valid[p] ? ld4s<NT>(YI + off[p]) : zero4();
+            yr[p] = valid[p] ? ld4s<NT>(YR + off[p]) : zero4();
             zi[p] = valid[p] ? ld4g(ZI + off[p]) : zero4();
         }
         ai[0] = gather_row64(rowptr, col, ZI + (size_t)base * 64, node[0], valid[0], sub);
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(256) void k_step64(const int* __restrict__ rowptr, 
             yi[p].x += dt * dI.x; yi[p].y += dt * dI.y; yi[p].z += dt * dI.z; yi[p].w += dt * dI.w;
             yr[p].x += dt * dR.x; yr[p].y += dt * dR.y; yr[p].z += dt * dR.z; yr[p].w += dt * dR.w;
             if (valid[p]) {
-                st4g(YS + off[p], ys[p]); st4g(YI + off[p], yi[p]); st4g(YR + off[p], yr[p]);
+                st4s<NT>(YS + off[p], ys[p]); st4s<NT>(YI + off[p], yi[p]); st4s<NT>(YR + off[p], yr[p]);
                 if (out.sol) { st4g(out.sol + off[p], ys[p]); st4g(out.sol + slab + off[p], yi[p]); st4g(out.sol + 2 * slab + off[p], yr[p]); }
             }
             if (out.S) {
@@ -306,14 +318,14 @@ int gn_launch_step64(const gnode_graph_s* g, long rows, float* Y, const float* Z
     const long total = (long)(rows / g->n) * tps;
     const int k = wgs_per_cu();
     const int grid = (int)(k > 0 ? std::min<long>(total, (long)num_cus() * k) : total);
-    if (fuse)
-        hipLaunchKernelGGL(k_step64<true>, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI,
-                           ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,
-                           p->linearS2_bias, out);
-    else
-        hipLaunchKernelGGL(k_step64<false>, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI,
-                           ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,
-                           p->linearS2_bias, out);
+    static const bool nt = [] { const char* e = getenv("GNODE_NT"); return e ? e[0] != '0' : true; }();
+#define GN_STEP(F, N)                                                                                                       \
+    hipLaunchKernelGGL((k_step64<F, N>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI,   \
+                       ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,          \
+                       p->linearS2_bias, out)
+    if (fuse) { if (nt) GN_STEP(true, true); else GN_STEP(true, false); }
+    else { if (nt) GN_STEP(false, true); else GN_STEP(false, false); }
+#undef GN_STEP
     GN_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,358 @@
+"""Trainer plumbing around the hot path: what the reference's L3
+scripts do around `model(x)` -- dataset assembly, splits, Adam/L1 loop, best-val -> test,
+CSV rows -- restated as a library so the drop-in entry scripts stay thin.
+
+    single graph : ode_nn_ngraph_sim.py:323-486   (monitorer-sim.py, model='ode_nn')
+    multi graph  : ode_nn_ngraphs.py:291-415      (monitorer-ngraphs.py, model='ode_nn')
+
+Differences that are deliberate (and invisible to the file/argv contract):
+  * the row subsample of get_sir_t_nodes_torch (ode_nn.py:249-261) is fused into the
+    forward (`out_rows`), and the loss is assembled on the GPU (no per-row D2H copies);
+  * under torch.distributed (one process per GPU) every batch is sharded over ranks and
+    the 4 809-float gradient is all-reduced once per optimiser step (RCCL over xGMI);
+    with WORLD_SIZE=1 this is exactly the reference's single-device loop.
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, sharding
+from .ode_nn import create_graph, sir_torch
+
+
+# --------------------------------------------------------------------------- CSV (ode_nn.py:374-392)
+def csv_trials(path_to_csv, columns, list_to_csv):
+    new = not os.path.exists(path_to_csv)
+    with open(path_to_csv, "w" if new else "a+", newline="") as fh:
+        w = csv.writer(fh)
+        if new:
+            w.writerow(columns)
+        w.writerow(list_to_csv)
+
+
+def save_trial_to_csv(args, best_epoch, val_loss, test_loss, loss_baseline, n_ode_time, rk_time):
+    row = [args.trial, args.model, args.lr, args.epochs, args.sim, args.train_val_test_ratio, len(args.beta), len(args.gamma),
+           args.deltaT, args.maxTime, [len(args.I_indices[0]), len(args.I_indices)], args.hidden, best_epoch, val_loss,
+           test_loss, loss_baseline, n_ode_time, rk_time]
+    csv_trials(args.path_to_save + "/Metrics-trials-" + os.path.relpath(args.dataset, "./real_graphs/"),
+               ["trial", "model", "lr", "epochs", "MC sim", "train_val_test_ratio", "beta", "gamma", "deltaT", "maxTime",
+                "I_indices", "hidden", "best_epoch", "val_loss", "test_loss", "loss_baseline", "n_ode_time", "rk_time"], row)
+
+
+# --------------------------------------------------------------------------- labels (ode_nn_ngraph_sim.py:190-206)
+def label_paths(dataset, path_to_save, I_indices):
+    stem = path_to_save + "/" + dataset[14:] + "-{}-" + "-".join(str(i) for i in I_indices) + ".pkl"
+    return [stem.format(c) for c in "SIR"]
+
+
+def load_SIR_labels(dataset, path_to_save, G, I_indices, beta, gamma, sim, maxTime):
+    """Label cache keyed by the seed set only (reference quirk Q4): load the three
+    [T, n] probability arrays if present, else generate them with the Monte-Carlo kernel,
+    divide the counts by `sim` (ode_nn_ngraph_sim.py:199) and write the same files."""
+    ps = label_paths(dataset, path_to_save, I_indices)
+    if os.path.exists(ps[0]):
+        return tuple(pickle.load(open(p, "rb")) for p in ps)
+    S, I, R = sir_torch(G, I_indices, beta, gamma, sim, maxTime)
+    out = (S[0] / sim, I[0] / sim, R[0] / sim)
+    for p, a in zip(ps, out):
+        pickle.dump(a, open(p, "wb"))
+    return out
+
+
+# --------------------------------------------------------------------------- dataset assembly
+def sample_tensor(n_nodes, hidden, seeds, beta, gamma, marker=None):
+    """x_i = [S0 | I0 | R0 | beta-gamma slab] in [n, 3+H] (ode_nn_ngraph_sim.py:373-390;
+    multi-graph marker at slab column 2 of node 0, ode_nn_ngraphs.py:333)."""
+    x = torch.zeros(n_nodes, 3 + hidden, dtype=torch.float32)
+    x[:, 0] = 1.0
+    x[list(seeds), 0] = 0.0
+    x[list(seeds), 1] = 1.0
+    x[:, 3] = beta
+    x[:, 4] = gamma
+    if marker is not None:
+        x[0, 5] = marker
+    return x
+
+
+def split_indices(n_items, ratio, out_of_dist=None):
+    """Sequential split by ratio (ode_nn_ngraph_sim.py:385-397) or by the index dict of
+    out-of-dist-gamma.pkl (:399-414)."""
+    if out_of_dist is not None:
+        tr = [i for i in range(n_items) if i in out_of_dist["train"]]
+        va = [i for i in range(n_items) if i in out_of_dist["val"]]
+        te = [i for i in range(n_items) if i not in out_of_dist["train"] and i not in out_of_dist["val"]]
+        return tr, va, te
+    a = int(ratio[0] * n_items)
+    b = int((ratio[0] + ratio[1]) * n_items)
+    return list(range(0, a)), list(range(a, b)), list(range(b, n_items))
+
+
+# --------------------------------------------------------------------------- epoch loops
+class Runner:
+    """model + optimiser + the epoch loops of the reference (train :208-270, test :272-296).
+
+    `stack=True`: single-graph batches [B, n, 3+H] (DataLoader of ode_nn_ngraph_sim.py:416-429);
+    `stack=False`: multi-graph batches concatenated along the node axis (ode_nn_ngraphs.py:179-196).
+    Under torch.distributed every batch's samples are split into contiguous per-rank blocks; each
+    rank back-propagates its share of the GLOBAL element-mean L1 (:234, :248-249) and the gradients
+    are summed with one flat all-reduce."""
+
+    def __init__(self, model, lr, maxTime, deltaT, device, stack):
+        self.model, self.device, self.stack = model, device, stack
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr)
+        self.rows = ops.subsample_rows(maxTime, deltaT)
+        self.rank, self.world = sharding.world_info()
+        seed = torch.randint(0, 2**31 - 1, (1,))
+        if self.world > 1:
+            torch.distributed.broadcast(seed, src=0)
+        self.seed = int(seed.item())
+
+    def batches(self, n_items, batch_size, shuffle, epoch=0):
+        if shuffle:
+            g = torch.Generator().manual_seed(self.seed + epoch)       # same permutation on every rank
+            idx = torch.randperm(n_items, generator=g).tolist()
+        else:
+            idx = list(range(n_items))
+        return [idx[i:i + batch_size] for i in range(0, n_items, batch_size)]
+
+    def _local(self, xs, ys, sel):
+        lo, hi = sharding.shard_range(len(sel), self.rank, self.world)
+        mine = sel[lo:hi]
+        if not mine:
+            return None, None
+        x = torch.stack([xs[j] for j in mine]) if self.stack else torch.cat([xs[j] for j in mine], 0)
+        y = torch.cat([ys[j] for j in mine], 0)
+        return x.to(self.device), y.to(self.device)
+
+    def _loss_sum(self, x, y):
+        S, I, R = self.model(x, out_rows=self.rows)
+        pred = torch.cat((S, I, R), -1).transpose(0, 1)[:, 1:, :]       # [rows, T-1, 3], t = 0 excluded (:234)
+        tgt = y[:, 1:, :]
+        return (pred.to(tgt.dtype) - tgt).abs().sum()
+
+    def _global_sum(self, value):
+        if self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        torch.distributed.all_reduce(t)
+        return float(t[0])
+
+    def train_epoch(self, xs, ys, batch_size, epoch):
+        self.model.train()
+        tot, items, t_fwd = 0.0, 0, 0.0
+        T = ys[0].shape[1] if ys else 0
+        for sel in self.batches(len(xs), batch_size, True, epoch):
+            self.opt.zero_grad()
+            gcount = sum(ys[j].shape[0] for j in sel) * (T - 1) * 3       # elements of the GLOBAL batch
+            x, y = self._local(xs, ys, sel)
+            lsum = 0.0
+            if x is not None:
+                t0 = time.time()
+                ls = self._loss_sum(x, y)
+                t_fwd += time.time() - t0
+                (ls / gcount).backward()
+                lsum = float(ls.detach())
+            if self.world > 1:
+                for p in self.model.parameters():                        # ranks without samples contribute zeros
+                    if p.grad is None and p.requires_grad:
+                        p.grad = torch.zeros_like(p)
+                sharding.allreduce_flat_grads([p for p in self.model.parameters() if p.grad is not None])
+            self.opt.step()
+            tot += self._global_sum(lsum)
+            items += gcount
+        return tot / max(items, 1), t_fwd
+
+    @torch.no_grad()
+    def evaluate(self, xs, ys, batch_size):
+        self.model.eval()
+        tot, items, per_batch = 0.0, 0, []
+        T = ys[0].shape[1] if ys else 0
+        for sel in self.batches(len(xs), batch_size, False):
+            gcount = sum(ys[j].shape[0] for j in sel) * (T - 1) * 3
+            x, y = self._local(xs, ys, sel)
+            lsum = self._global_sum(float(self._loss_sum(x, y)) if x is not None else 0.0)
+            tot += lsum
+            items += gcount
+            per_batch.append(lsum / max(gcount, 1))
+        return tot / max(items, 1), per_batch
+
+
+# --------------------------------------------------------------------------- single-graph entry (ode_nn_ngraph_sim.py:323-486)
+def parser_single():
+    p = argparse.ArgumentParser(description="Neural ODE")
+    p.add_argument("--lr", type=float, default=1e-2)
+    p.add_argument("--epochs", type=int, default=100)
+    p.add_argument("--sim", type=int, default=1000)
+    p.add_argument("--beta", type=float, nargs="+", default=[0.2])
+    p.add_argument("--gamma", type=float, nargs="+", default=[0.1])
+    p.add_argument("--deltaT", type=float, default=0.5)
+    p.add_argument("--maxTime", type=int, default=20)
+    p.add_argument("--I_indices", nargs="+", default=[12])
+    p.add_argument("--hidden", type=int, default=32)
+    p.add_argument("--batch_size", type=int, default=32)
+    p.add_argument("--path_to_save", default="./plots")
+    p.add_argument("--trial", type=int, default=32)
+    p.add_argument("--dataset", default="none")
+    p.add_argument("--train_val_test_ratio", nargs=3, type=float, default=[5e-1, 1e-1, 4e-1])
+    p.add_argument("--model", default="ode_nn", type=str)
+    p.add_argument("--out_of_dist", default=False, action="store_true")
+    return p
+
+
+def main_single(argv=None):
+    from .ode_nn_ngraph_sim import ODEBlock, ODEfunc
+    args = parser_single().parse_args(argv)
+    if args.model != "ode_nn":
+        raise SystemExit(f"this entry point serves model='ode_nn' only (got {args.model!r})")
+    G, A, _ = create_graph(50, args.dataset)
+    n_nodes = A.shape[0]
+    print(n_nodes)
+    args.I_indices = [list(map(int, str(i)[1:-1].split(", "))) for i in args.I_indices]      # "[25, 18]" -> [25, 18]
+    if not os.path.exists(args.path_to_save + "/initial-seed.pkl"):
+        pickle.dump(args.I_indices, open(args.path_to_save + "/initial-seed.pkl", "wb"))
+        pickle.dump(args.beta, open(args.path_to_save + "/initial-beta.pkl", "wb"))
+        pickle.dump(args.gamma, open(args.path_to_save + "/initial-gamma.pkl", "wb"))
+    xs, ys = [], []
+    for i, seeds in enumerate(args.I_indices):
+        S, I, R = load_SIR_labels(args.dataset, args.path_to_save, G, seeds, args.beta[i], args.gamma[i], args.sim, args.maxTime)
+        y = torch.from_numpy(np.stack([np.asarray(S), np.asarray(I), np.asarray(R)], -1)).transpose(0, 1)   # [n, T, 3] float64
+        xs.append(sample_tensor(n_nodes, args.hidden, seeds, args.beta[i], args.gamma[i]))
+        ys.append(y.contiguous())
+    ood = pickle.load(open(args.path_to_save + "/out-of-dist-gamma.pkl", "rb")) if args.out_of_dist else None
+    tr, va, te = split_indices(len(xs), args.train_val_test_ratio, ood)
+    device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    torch.set_default_dtype(torch.float32)
+    print(device)
+    odefunc = ODEfunc(A, args.beta[0], args.gamma[0], args.hidden, device)
+    model = ODEBlock(args.maxTime, args.deltaT, n_nodes, args.I_indices[0], args.hidden, odefunc, device).to(device)
+    run = Runner(model, args.lr, args.maxTime, args.deltaT, device, stack=True)
+    pick = lambda ids: ([xs[i] for i in ids], [ys[i] for i in ids])
+    best_loss, best_epoch, test_loss, test_all, t_test = np.inf, -1, float("nan"), [], 0.0
+    print("training...")
+    for epoch in range(args.epochs):
+        loss, t_fwd = run.train_epoch(*pick(tr), args.batch_size, epoch)
+        val_loss, _ = run.evaluate(*pick(va), args.batch_size)
+        print("Time: ", t_fwd)
+        print("Epoch: {:03d}, Train Loss: {:.10f}, Val Loss: {:.10f}".format(epoch, loss, val_loss))
+        if val_loss < best_loss:
+            best_loss, best_epoch = val_loss, epoch
+            t0 = time.time()
+            test_loss, test_all = run.evaluate(*pick(te), 1)
+            t_test = time.time() - t0
+    if not args.out_of_dist:
+        save_trial_to_csv(args, best_epoch, best_loss, test_loss, 0, t_test, 0)
+    else:
+        rel = os.path.relpath(args.dataset, "./real_graphs/")
+        csv_trials(args.path_to_save + "/Out-of-dist-gamma-" + rel, [str(i) for i in ood["test"]], test_all)
+        csv_trials(args.path_to_save + "/Out-of-dist-gamma-trials-" + rel,
+                   ["trial", "model", "lr", "epochs", "deltaT", "maxTime", "hidden", "best_epoch", "val_loss", "test_loss", "n_ode_time"],
+                   [args.trial, args.model, args.lr, args.epochs, args.deltaT, args.maxTime, args.hidden, best_epoch, best_loss,
+                    test_loss, t_test])
+    return 0
+
+
+# --------------------------------------------------------------------------- multi-graph entry (ode_nn_ngraphs.py:291-415)
+def parser_multi():
+    p = argparse.ArgumentParser(description="Neural ODE")
+    p.add_argument("--lr", type=float, default=1e-2)
+    p.add_argument("--epochs", type=int, default=100)
+    p.add_argument("--sim", type=int, default=1000)
+    p.add_argument("--deltaT", type=float, default=0.5)
+    p.add_argument("--maxTime", type=int, default=20)
+    p.add_argument("--hidden", type=int, default=32)
+    p.add_argument("--batch_size", type=int, default=32)
+    p.add_argument("--path_to_save", default="./plots")
+    p.add_argument("--trial", type=int, default=32)
+    p.add_argument("--dataset", default="none")
+    p.add_argument("--train_val_test_ratio", nargs=3, type=float, default=[5e-1, 1e-1, 4e-1])
+    p.add_argument("--model", default="ode_nn", type=str)
+    p.add_argument("--instances_per_graph", type=int, nargs="+", default=[36, 36, 36, 36, 36, 120],
+                   help="extension: the reference hard-codes this list (ode_nn_ngraphs.py:311)")
+    p.add_argument("--per_sample_seeds", action="store_true",
+                   help="extension: use each sample's own seed set; the reference infects ALL sampled seeds of a graph "
+                        "in every sample (quirk Q5, ode_nn_ngraphs.py:343), which stays the default")
+    return p
+
+
+def load_multi_labels(dataset, path_to_save, I_indices, sim):
+    """ode_nn_ngraphs.py:167-177: labels are only loaded; wiki-vote files hold raw counts."""
+    div = sim if dataset == "wiki-vote" else 1
+    stem = path_to_save + "/" + dataset + "-{}-" + "-".join(str(i) for i in I_indices) + ".pkl"
+    return tuple(pickle.load(open(stem.format(c), "rb")) / div for c in "SIR")
+
+
+def main_multi(argv=None):
+    import networkx as nx
+    from .ode_nn_ngraphs import ODEBlock, ODEfunc
+    args = parser_multi().parse_args(argv)
+    if args.model != "ode_nn":
+        raise SystemExit(f"this entry point serves model='ode_nn' only (got {args.model!r})")
+    names = args.dataset[14:].split("+")
+    A_list = []
+    for gname in names:                                             # create_graphs, ode_nn_ngraphs.py:154-165
+        _, A, _ = create_graph(0, args.dataset[:14] + gname)
+        A_list.append(A)
+    print(len(A_list))
+    ipg = args.instances_per_graph
+    n_train_graphs = len(ipg) - 2
+    val_len = int(ipg[-1] / 2)
+    tr, va, te = ([], []), ([], []), ([], [])
+    count_val = 0
+    for gi, gname in enumerate(names):
+        if gname == "wiki-vote":
+            path_load = "./multi-graph-1/Experiments-gpu-seed2"
+        elif gname == "enron":
+            path_load = "./multi-graph-1/Experiments2-seed2"
+        else:
+            last = args.path_to_save.split("/")[-1].split("-")
+            path_load = "./multi-graph-1/" + last[0] + "-" + last[1]
+        d = path_load + "-" + gname
+        I_all = pickle.load(open(d + "/initial-seed.pkl", "rb"))[:ipg[gi]]
+        betas = pickle.load(open(d + "/initial-beta.pkl", "rb"))[:ipg[gi]]
+        gammas = pickle.load(open(d + "/initial-gamma.pkl", "rb"))[:ipg[gi]]
+        n_nodes = A_list[gi].shape[0]
+        for i, indices in enumerate(I_all):
+            S, I, R = load_multi_labels(gname, d, indices, args.sim)
+            y = torch.from_numpy(np.stack([np.asarray(S), np.asarray(I), np.asarray(R)], -1)).transpose(0, 1).contiguous()
+            seeds = indices if args.per_sample_seeds else [s for grp in I_all for s in (grp if isinstance(grp, (list, tuple)) else [grp])]
+            x = sample_tensor(n_nodes, args.hidden, seeds, betas[i], gammas[i], marker=gi + 1)
+            if gi <= n_train_graphs:
+                dst = tr
+            elif count_val < val_len:
+                dst = va
+                count_val += 1
+            else:
+                dst = te
+            dst[0].append(x)
+            dst[1].append(y)
+    device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    torch.set_default_dtype(torch.float32)
+    print(device)
+    odefunc = ODEfunc(A_list, args.hidden, device)
+    model = ODEBlock(args.maxTime, args.deltaT, args.hidden, odefunc, device).to(device)
+    run = Runner(model, args.lr, args.maxTime, args.deltaT, device, stack=False)
+    best_loss, best_epoch, test_loss, t_test = np.inf, -1, float("nan"), 0.0
+    print("training...")
+    for epoch in range(args.epochs):
+        loss, t_fwd = run.train_epoch(tr[0], tr[1], args.batch_size, epoch)
+        val_loss, _ = run.evaluate(va[0], va[1], args.batch_size)
+        print("Time: ", t_fwd)
+        print("Epoch: {:03d}, Train Loss: {:.10f}, Val Loss: {:.10f}".format(epoch, loss, val_loss))
+        if val_loss < best_loss:
+            best_loss, best_epoch = val_loss, epoch
+            t0 = time.time()
+            test_loss, _ = run.evaluate(te[0], te[1], args.batch_size)
+            t_test = time.time() - t0
+    csv_trials(args.path_to_save + "/Metrics-trials-" + os.path.relpath(args.dataset, "./real_graphs/"),
+               ["trial", "model", "lr", "epochs", "deltaT", "maxTime", "hidden", "best_epoch", "val_loss", "test_loss", "n_ode_time"],
+               [args.trial, args.model, args.lr, args.epochs, args.deltaT, args.maxTime, args.hidden, best_epoch, best_loss,
+                test_loss, t_test])
+    return 0

@@ -1,0 +1,93 @@
+"""GPU: the drop-in entry points keep the reference's argv/file contract
+(monitorer-sim.py:53-103 -> ode_nn_ngraph_sim.py:326-356; monitorer-ngraphs.py:49-87 ->
+ode_nn_ngraphs.py:296-308).  Graph/label pickles here are written by the test itself."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _mk_graph(path, n, m, seed):
+    import networkx as nx
+    G = nx.gnm_random_graph(n, m, seed=seed)
+    G = nx.convert_node_labels_to_integers(G.subgraph(max(nx.connected_components(G), key=len)).copy(), ordering="sorted")
+    pickle.dump(G, open(path, "wb"))
+    return G
+
+
+def test_single_graph_entry_point(tmp_path, monkeypatch, dev):
+    import pandas as pd
+    from gnode.trainer import main_single
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("real_graphs"); os.makedirs("multi-graph-1/Experiments-seed2-toy")
+    G = _mk_graph("real_graphs/toy.pkl", 80, 240, 1)
+    n = G.number_of_nodes()
+    rng = np.random.default_rng(0)
+    seeds = [sorted(rng.choice(n, 2, replace=False).tolist()) for _ in range(10)]
+    argv = ["--lr", "0.01", "--epochs", "3", "--hidden", "64", "--I_indices"] + [str(s) for s in seeds] + \
+           ["--beta"] + [f"{b:.3f}" for b in rng.uniform(0.1, 0.5, 10)] + ["--gamma"] + [f"{g:.3f}" for g in rng.uniform(0.1, 0.5, 10)] + \
+           ["--deltaT", "0.5", "--maxTime", "8", "--sim", "200", "--trial", "0", "--dataset", "./real_graphs/toy",
+            "--path_to_save", "./multi-graph-1/Experiments-seed2-toy", "--batch_size", "4",
+            "--train_val_test_ratio", "0.6", "0.2", "0.2", "--model", "ode_nn"]
+    assert main_single(argv) == 0
+    d = "multi-graph-1/Experiments-seed2-toy"
+    assert pickle.load(open(d + "/initial-seed.pkl", "rb")) == seeds                      # ode_nn_ngraph_sim.py:353-356
+    for s in seeds:
+        for c in "SIR":
+            a = pickle.load(open(f"{d}/toy-{c}-{s[0]}-{s[1]}.pkl", "rb"))                 # label cache naming :191-204
+            assert a.shape == (8, n) and a.dtype == np.float64 and a.min() >= 0 and a.max() <= 1
+    df = pd.read_csv(d + "/Metrics-trials-toy")
+    assert list(df.columns)[:4] == ["trial", "model", "lr", "epochs"] and len(df) == 1 and df["model"][0] == "ode_nn"
+    assert np.isfinite(df["test_loss"][0]) and df["test_loss"][0] < 0.5
+    # second trial appends a row and reuses the label cache
+    argv[argv.index("--trial") + 1] = "1"
+    assert main_single(argv) == 0
+    assert len(pd.read_csv(d + "/Metrics-trials-toy")) == 2
+    # out-of-distribution split
+    pickle.dump({"train": [0, 1, 2, 3, 4], "val": [5, 6], "test": [7, 8, 9]}, open(d + "/out-of-dist-gamma.pkl", "wb"))
+    assert main_single(argv + ["--out_of_dist"]) == 0
+    assert os.path.exists(d + "/Out-of-dist-gamma-toy") and os.path.exists(d + "/Out-of-dist-gamma-trials-toy")
+
+
+def test_multi_graph_entry_point(tmp_path, monkeypatch, dev):
+    import pandas as pd
+    from gnode.trainer import main_multi
+    from gnode.ode_nn import sir_torch
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("real_graphs")
+    names, sizes = ["ga", "gb", "gc"], [(40, 100), (70, 220), (55, 150)]
+    ipg = [3, 3, 4]                                   # train: ga, gb ; val 2 + test 2 from gc
+    rng = np.random.default_rng(3)
+    for (name, (n, m)) in zip(names, sizes):
+        G = _mk_graph(f"real_graphs/{name}.pkl", n, m, 5)
+        d = f"multi-graph-1/Experiments-seed2-{name}"
+        os.makedirs(d)
+        k = max(ipg)
+        seeds = [sorted(rng.choice(G.number_of_nodes(), 2, replace=False).tolist()) for _ in range(k)]
+        betas, gammas = rng.uniform(0.1, 0.5, k).tolist(), rng.uniform(0.1, 0.5, k).tolist()
+        pickle.dump(seeds, open(d + "/initial-seed.pkl", "wb"))
+        pickle.dump(betas, open(d + "/initial-beta.pkl", "wb"))
+        pickle.dump(gammas, open(d + "/initial-gamma.pkl", "wb"))
+        for s, b, g in zip(seeds, betas, gammas):
+            S, I, R = sir_torch(G, s, b, g, 100, 6)
+            for c, a in zip("SIR", (S, I, R)):
+                pickle.dump(a[0] / 100, open(f"{d}/{name}-{c}-{s[0]}-{s[1]}.pkl", "wb"))
+    argv = ["--lr", "0.01", "--epochs", "2", "--hidden", "8", "--deltaT", "0.5", "--maxTime", "6", "--sim", "100",
+            "--trial", "0", "--dataset", "./real_graphs/ga+gb+gc", "--path_to_save", "./multi-graph-1/Experiments-seed2-ga+gb+gc",
+            "--batch_size", "2", "--train_val_test_ratio", "0.6", "0.2", "0.2", "--model", "ode_nn",
+            "--instances_per_graph"] + [str(v) for v in ipg]
+    os.makedirs("multi-graph-1/Experiments-seed2-ga+gb+gc")
+    assert main_multi(argv) == 0
+    df = pd.read_csv("multi-graph-1/Experiments-seed2-ga+gb+gc/Metrics-trials-ga+gb+gc")
+    assert len(df) == 1 and np.isfinite(df["test_loss"][0])

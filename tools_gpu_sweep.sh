@@ -1,23 +1,20 @@
 #!/bin/bash
-# bench variants back to back in one box (same device): each line = one JSON result
+# bench variants back to back in one box (same device): each line = one result
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
-run() { echo "== $*"; env "$@" timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline $BARGS 2>gpurun_out/sweep.err | python -c "
+run() { echo "== $*"; env "$@" timeout -k 10 300 python bench.py --steps ${STEPS:-4} --warmup 1 --no-cpu-baseline $BARGS 2>gpurun_out/sweep.err | python -c "
 import sys, json
 for l in sys.stdin:
     l=l.strip()
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']
-        print('value %.3e  ms/step %.2f  step_us %.1f  mlp_us %.1f  frac %.3f chunk %s' % (d['value'], d['ms_per_step'], r['avg_launch_us'], r['node_mlp_avg_launch_us'], r['frac'], d['config']['samples_per_launch']))
+        print('value %.4e  ms/step %.2f  step_us %.1f  mlp_us %.1f  frac %.3f chunk %s' % (d['value'], d['ms_per_step'], r['avg_launch_us'], r['node_mlp_avg_launch_us'], r['frac'], d['config']['samples_per_launch']))
 "; }
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/test.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -n 4 gpurun_out/test.log
-if [ $rc -ge 124 ]; then exit $rc; fi
-run GNODE_FUSE=1 GNODE_WGS_PER_CU=4
-run GNODE_FUSE=0 GNODE_WGS_PER_CU=4
-run GNODE_FUSE=1 GNODE_WGS_PER_CU=0
-run GNODE_FUSE=0 GNODE_WGS_PER_CU=0
-run GNODE_FUSE=1 GNODE_WGS_PER_CU=3
-run GNODE_FUSE=1 GNODE_WGS_PER_CU=4 GNODE_CHUNK=2
-run GNODE_FUSE=1 GNODE_WGS_PER_CU=0 GNODE_CHUNK=2
-run GNODE_FUSE=1 GNODE_WGS_PER_CU=4 GNODE_CHUNK=4
-run GNODE_FUSE=1 GNODE_WGS_PER_CU=4 GNODE_CHUNK=8
+for i in 1 2; do
+run GNODE_NT=0
+run GNODE_NT=1
+done
+run GNODE_NT=1 GNODE_WGS_PER_CU=0
+run GNODE_NT=0 GNODE_WGS_PER_CU=0
+run GNODE_NT=1 GNODE_CHUNK=4
+run GNODE_NT=1 GNODE_CHUNK=1
