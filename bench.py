@@ -30,12 +30,14 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def algorithmic_bytes_per_sample_step(n, nnz, H):
-    """Dominant kernel (CSR pull-gather + SIR derivative + Euler update + read-out), one
-    sample, one Euler step, fp32 / int32 CSR (DESIGN.md "Kernels"):
-    col nnz*4 + rowptr (n+1)*4 + neighbour rows nnz*H*4   (the edge-gather step)
-    + own Z_S, Z_I rows 2*n*H*4 + state read 3*n*H*4 + state write 3*n*H*4."""
-    return nnz * 4 + (n + 1) * 4 + nnz * H * 4 + 8 * n * H * 4
+def algorithmic_bytes_per_sample_step(n, nnz, H, projected_R=True):
+    """Dominant kernel (fused Euler step), one sample, one step, fp32 / int32 CSR (DESIGN.md
+    "Kernels"):  col nnz*4 + rowptr (n+1)*4 + neighbour rows nnz*H*4  (the edge-gather
+    step) + own Z_I row + Y_S, Y_I read + write + next-step Z_I write = 6*n*H*4, + the R
+    compartment: Y_R read + write 2*n*H*4, or its 4-float read-out projection 2*n*16 in
+    inference mode (no trajectory requested)."""
+    r_bytes = 2 * n * 16 if projected_R else 2 * n * H * 4
+    return nnz * 4 + (n + 1) * 4 + nnz * H * 4 + 6 * n * H * 4 + r_bytes
 
 
 def main():
@@ -138,7 +140,8 @@ def main():
     units = world * B * n * n_steps * args.steps
     value = units / elapsed
     gather_avg_s = (gms.value / max(gcnt.value, 1)) * 1e-3
-    alg_bytes = algorithmic_bytes_per_sample_step(n, nnz, H) * chunk
+    prj = os.environ.get("GNODE_PRJ", "1") != "0" and H == 64
+    alg_bytes = algorithmic_bytes_per_sample_step(n, nnz, H, prj) * chunk
     achieved = alg_bytes / gather_avg_s / 1e9 if gather_avg_s > 0 else 0.0
 
     # HBM-side traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside

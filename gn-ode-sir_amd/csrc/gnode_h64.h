@@ -10,4 +10,6 @@ struct Step64Out {
 int gn_launch_mlp64(const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st);
 int gn_launch_step64(const gnode_graph_s* g, long rows, float* Y, const float* ZI, float* ZI_next, const float* W,
                      const float* bias, const float* beta, const float* gamma, float dt, const gnode_params* p,
-                     Step64Out out, bool fuse, hipStream_t st);
+                     float* PR /* [rows][4] projected R state, or null = carry Y_R */, Step64Out out, bool fuse,
+                     hipStream_t st);
+int gn_launch_init_pr64(const float* YR, const float* w3, float* PR, long rows, hipStream_t st);

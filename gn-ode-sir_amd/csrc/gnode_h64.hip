@@ -173,19 +173,23 @@ __global__ __launch_bounds__(256) void k_mlp64(const float* __restrict__ X, cons
 }
 
 // --------------------------------------------------------------------------- k_step64
-__device__ __forceinline__ void readout64(float4 yS, float4 yI, float4 yR, int sub, const float* __restrict__ w3,
-                                          const float* __restrict__ b3, const float* __restrict__ w2,
-                                          const float* __restrict__ b2, float& pS, float& pI, float& pR) {
+// PRJ: the R compartment arrives already projected (prj[k] = w3[k] . Y_R, see k_step64's PRJ mode)
+template <bool PRJ>
+__device__ __forceinline__ void readout64(float4 yS, float4 yI, float4 yR, const float (&prj)[4], int sub,
+                                          const float* __restrict__ w3, const float* __restrict__ b3,
+                                          const float* __restrict__ w2, const float* __restrict__ b2, float& pS,
+                                          float& pI, float& pR) {
     float qS = b2[0], qI = qS, qR = qS;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float4 wv = ld4g(w3 + k * 64 + 4 * sub);
         float s = fmaf(wv.x, yS.x, fmaf(wv.y, yS.y, fmaf(wv.z, yS.z, wv.w * yS.w)));
         float i = fmaf(wv.x, yI.x, fmaf(wv.y, yI.y, fmaf(wv.z, yI.z, wv.w * yI.w)));
-        float r = fmaf(wv.x, yR.x, fmaf(wv.y, yR.y, fmaf(wv.z, yR.z, wv.w * yR.w)));
+        float r;
         s = row_sum16(s) + b3[k];
         i = row_sum16(i) + b3[k];
-        r = row_sum16(r) + b3[k];
+        if (PRJ) r = prj[k] + b3[k];
+        else r = row_sum16(fmaf(wv.x, yR.x, fmaf(wv.y, yR.y, fmaf(wv.z, yR.z, wv.w * yR.w)))) + b3[k];
         qS = fmaf(w2[k], fmaxf(s, 0.f), qS);
         qI = fmaf(w2[k], fmaxf(i, 0.f), qI);
         qR = fmaf(w2[k], fmaxf(r, 0.f), qR);
@@ -196,8 +200,8 @@ __device__ __forceinline__ void readout64(float4 yS, float4 yI, float4 yR, int s
     pS = eS * inv; pI = eI * inv; pR = eR * inv;
 }
 
-template <bool FUSE, bool NT>
-__global__ __launch_bounds__(256) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+template <bool FUSE, bool NT, bool PRJ>
+__global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                 long rows, int tiles_per_sample, long total_tiles,
                                                 float* __restrict__ Y, const float* __restrict__ ZI,
                                                 float* __restrict__ ZI_next, const float* __restrict__ W,
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void k_step64(const int* __restrict__ rowptr, 
                                                 const float* __restrict__ gamma, float dt,
                                                 const float* __restrict__ w3, const float* __restrict__ b3,
                                                 const float* __restrict__ w2, const float* __restrict__ b2,
-                                                Step64Out out) {
+                                                float* __restrict__ PR, Step64Out out) {
     __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
     __shared__ __attribute__((aligned(16))) float T[TILE_ROWS * TS];
     __shared__ __attribute__((aligned(16))) float T2[TILE_ROWS * TS];
@@ -214,6 +218,7 @@ __global__ __launch_bounds__(256) void k_step64(const int* __restrict__ rowptr, 
     const float bias_l = bias[16 * w + (lane & 15)];
     const size_t slab = (size_t)rows * 64;
     float* YS = Y; float* YI = Y + slab; float* YR = Y + 2 * slab;
+
     const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
 
     for (long t = blockIdx.x; t < total_tiles; t += gridDim.x) {
@@ -234,9 +239,11 @@ __global__ __launch_bounds__(256) void k_step64(const int* __restrict__ rowptr, 
         for (int p = 0; p < 2; ++p) {
             *reinterpret_cast<float4*>(T + lr[p] * TS + 4 * sub) = ys[p];
             yi[p] = valid[p] ? ld4s<NT>(YI + off[p]) : zero4();
-            yr[p] = valid[p] ? ld4s<NT>(YR + off[p]) : zero4();
+            yr[p] = (!PRJ && valid[p]) ? ld4s<NT>(YR + off[p]) : zero4();
             zi[p] = valid[p] ? ld4g(ZI + off[p]) : zero4();
         }
+        // (measured: gathering the two rows in lockstep with 8 loads in flight per lane is 25 % SLOWER --
+        //  the memory system is already at its request-rate limit)
         ai[0] = gather_row64(rowptr, col, ZI + (size_t)base * 64, node[0], valid[0], sub);
         ai[1] = gather_row64(rowptr, col, ZI + (size_t)base * 64, node[1], valid[1], sub);
         __syncthreads();
@@ -255,14 +262,31 @@ __global__ __launch_bounds__(256) void k_step64(const int* __restrict__ rowptr, 
             dI.x = -dS.x - dR.x; dI.y = -dS.y - dR.y; dI.z = -dS.z - dR.z; dI.w = -dS.w - dR.w;
             ys[p].x += dt * dS.x; ys[p].y += dt * dS.y; ys[p].z += dt * dS.z; ys[p].w += dt * dS.w;
             yi[p].x += dt * dI.x; yi[p].y += dt * dI.y; yi[p].z += dt * dI.z; yi[p].w += dt * dI.w;
-            yr[p].x += dt * dR.x; yr[p].y += dt * dR.y; yr[p].z += dt * dR.z; yr[p].w += dt * dR.w;
+            float prj[4] = {0.f, 0.f, 0.f, 0.f};
+            if (PRJ) {
+                // R only feeds the read-out, and its first layer is linear: carry w3 . Y_R (4 floats per row)
+                // instead of Y_R (64):  w3 . (Y_R + dt*gamma*Z_I) = w3 . Y_R + dt*gamma*(w3 . Z_I)
+                float4 pr = zero4();
+                if (valid[p]) pr = ld4g(PR + (size_t)(base + node[p]) * 4);
+                float4 w3r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w3r[k] = ld4g(w3 + k * 64 + 4 * sub);   // L1-resident, shared with the read-out
+                prj[0] = pr.x + dt * (gm * row_sum16(fmaf(w3r[0].x, zi[p].x, fmaf(w3r[0].y, zi[p].y, fmaf(w3r[0].z, zi[p].z, w3r[0].w * zi[p].w)))));
+                prj[1] = pr.y + dt * (gm * row_sum16(fmaf(w3r[1].x, zi[p].x, fmaf(w3r[1].y, zi[p].y, fmaf(w3r[1].z, zi[p].z, w3r[1].w * zi[p].w)))));
+                prj[2] = pr.z + dt * (gm * row_sum16(fmaf(w3r[2].x, zi[p].x, fmaf(w3r[2].y, zi[p].y, fmaf(w3r[2].z, zi[p].z, w3r[2].w * zi[p].w)))));
+                prj[3] = pr.w + dt * (gm * row_sum16(fmaf(w3r[3].x, zi[p].x, fmaf(w3r[3].y, zi[p].y, fmaf(w3r[3].z, zi[p].z, w3r[3].w * zi[p].w)))));
+                if (valid[p] && sub == 0) st4g(PR + (size_t)(base + node[p]) * 4, make_float4(prj[0], prj[1], prj[2], prj[3]));
+            } else {
+                yr[p].x += dt * dR.x; yr[p].y += dt * dR.y; yr[p].z += dt * dR.z; yr[p].w += dt * dR.w;
+            }
             if (valid[p]) {
-                st4s<NT>(YS + off[p], ys[p]); st4s<NT>(YI + off[p], yi[p]); st4s<NT>(YR + off[p], yr[p]);
+                st4s<NT>(YS + off[p], ys[p]); st4s<NT>(YI + off[p], yi[p]);
+                if (!PRJ) st4s<NT>(YR + off[p], yr[p]);
                 if (out.sol) { st4g(out.sol + off[p], ys[p]); st4g(out.sol + slab + off[p], yi[p]); st4g(out.sol + 2 * slab + off[p], yr[p]); }
             }
             if (out.S) {
                 float pS, pI, pR;
-                readout64(ys[p], yi[p], yr[p], sub, w3, b3, w2, b2, pS, pI, pR);
+                readout64<PRJ>(ys[p], yi[p], yr[p], prj, sub, w3, b3, w2, b2, pS, pI, pR);
                 if (valid[p] && sub == 0) {
                     out.S[base + node[p]] = pS; out.I[base + node[p]] = pI; out.R[base + node[p]] = pR;
                 }
@@ -280,6 +304,27 @@ __global__ __launch_bounds__(256) void k_step64(const int* __restrict__ rowptr, 
         }
         __syncthreads();   // T / T2 are rewritten by the next tile
     }
+}
+
+// PR0[r][k] = w3[k] . Y_R[r]  (once per forward, PRJ mode)
+__global__ __launch_bounds__(256) void k_init_pr64(const float* __restrict__ YR, const float* __restrict__ w3,
+                                                   float* __restrict__ PR, long rows) {
+    const int sub = threadIdx.x & 15;
+    const long r = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const float4 y = r < rows ? ld4g(YR + (size_t)r * 64 + 4 * sub) : zero4();
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 wv = ld4g(w3 + k * 64 + 4 * sub);
+        v[k] = row_sum16(fmaf(wv.x, y.x, fmaf(wv.y, y.y, fmaf(wv.z, y.z, wv.w * y.w))));
+    }
+    if (r < rows && sub == 0) st4g(PR + (size_t)r * 4, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+int gn_launch_init_pr64(const float* YR, const float* w3, float* PR, long rows, hipStream_t st) {
+    hipLaunchKernelGGL(k_init_pr64, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, YR, w3, PR, rows);
+    GN_LAUNCH_CHECK();
+    return 0;
 }
 
 // --------------------------------------------------------------------------- host launchers
@@ -313,18 +358,21 @@ int gn_launch_mlp64(const float* X, const float* W, const float* b, float* Z, lo
 
 int gn_launch_step64(const gnode_graph_s* g, long rows, float* Y, const float* ZI, float* ZI_next, const float* W,
                      const float* bias, const float* beta, const float* gamma, float dt, const gnode_params* p,
-                     Step64Out out, bool fuse, hipStream_t st) {
+                     float* PR, Step64Out out, bool fuse, hipStream_t st) {
     const int tps = (g->n + TILE_ROWS - 1) / TILE_ROWS;
     const long total = (long)(rows / g->n) * tps;
     const int k = wgs_per_cu();
     const int grid = (int)(k > 0 ? std::min<long>(total, (long)num_cus() * k) : total);
     static const bool nt = [] { const char* e = getenv("GNODE_NT"); return e ? e[0] != '0' : true; }();
-#define GN_STEP(F, N)                                                                                                       \
-    hipLaunchKernelGGL((k_step64<F, N>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI,   \
-                       ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,          \
-                       p->linearS2_bias, out)
-    if (fuse) { if (nt) GN_STEP(true, true); else GN_STEP(true, false); }
-    else { if (nt) GN_STEP(false, true); else GN_STEP(false, false); }
+    const bool prj = PR != nullptr;
+#define GN_STEP(F, N, P)                                                                                                    \
+    hipLaunchKernelGGL((k_step64<F, N, P>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, \
+                       ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,           \
+                       p->linearS2_bias, PR, out)
+#define GN_STEP_P(F, N) do { if (prj) GN_STEP(F, N, true); else GN_STEP(F, N, false); } while (0)
+    if (fuse) { if (nt) GN_STEP_P(true, true); else GN_STEP_P(true, false); }
+    else { if (nt) GN_STEP_P(false, true); else GN_STEP_P(false, false); }
+#undef GN_STEP_P
 #undef GN_STEP
     GN_LAUNCH_CHECK();
     return 0;

@@ -534,7 +534,7 @@ extern "C" size_t gnode_forward_workspace_bytes(int64_t rows, int32_t H, int32_t
     const size_t slab = gn_align((size_t)rows * H * sizeof(float));
     size_t nslab = 5;                       // Y[3], Z[2]
     if (method == 1) nslab += 3 * 5;        // k1..k4, ytmp (3 slabs each)
-    return nslab * slab + 2 * gn_align((size_t)rows * sizeof(float));
+    return nslab * slab + 2 * gn_align((size_t)rows * sizeof(float)) + gn_align((size_t)rows * 4 * sizeof(float));
 }
 
 extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
@@ -571,7 +571,8 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
     float* Z = (float*)(ws + 3 * slab_b);
     float* beta = (float*)(ws + 5 * slab_b);
     float* gamma = (float*)(ws + 5 * slab_b + gn_align((size_t)rows * sizeof(float)));
-    float* rk = (float*)(ws + 5 * slab_b + 2 * gn_align((size_t)rows * sizeof(float)));
+    float* prbuf = (float*)(ws + 5 * slab_b + 2 * gn_align((size_t)rows * sizeof(float)));
+    float* rk = (float*)(ws + 5 * slab_b + 2 * gn_align((size_t)rows * sizeof(float)) + gn_align((size_t)rows * 4 * sizeof(float)));
 
     const int lpr = lpr_for(H), rpw = 256 / lpr;
     DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_encode<LPR>, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), 0, st, x,
@@ -594,8 +595,13 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
     static const bool fuse_zi = [] { const char* e = getenv("GNODE_FUSE"); return !(e && e[0] == '0'); }();
     float* zi_cur = Z;
     float* zi_nxt = Z + slab;
-    if (h64 && n_steps > 0)
+    // inference (no trajectory requested): R only feeds the read-out -> carry its 4-float projection
+    static const bool prj_ok = [] { const char* e = getenv("GNODE_PRJ"); return !(e && e[0] == '0'); }();
+    float* PR = (h64 && !sol && prj_ok) ? prbuf : nullptr;
+    if (h64 && n_steps > 0) {
         if (int e = launch_mlp(Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
+        if (PR) if (int e = gn_launch_init_pr64(Y + 2 * slab, p->linear3_weight, PR, rows, st)) return e;
+    }
 
     for (int k = 0; k < n_steps; ++k) {
         const float dt = dt_host[k];
@@ -606,7 +612,7 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
                              slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
             const bool sampled = prof_begin(0, st);
             if (int e = gn_launch_step64(g, rows, Y, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,
-                                         gamma, dt, p, out, fuse_zi, st))
+                                         gamma, dt, p, PR, out, fuse_zi, st))
                 return e;
             if (sampled) prof_mark(0, st);
             if (fuse_zi) std::swap(zi_cur, zi_nxt);
