@@ -19,6 +19,7 @@
 // launches (fixed grid, fixed row->workgroup map); one final kernel sums the slots in
 // order.  No float atomics, bitwise reproducible run to run.
 #include "gnode_common.h"
+#include "gnode_mfma64.h"
 #include <algorithm>
 
 #define BWD_NWG 512
@@ -274,6 +275,86 @@ __global__ __launch_bounds__(256) void k_bwd_mlp(const float* __restrict__ dpre,
     if (threadIdx.x < H) part[L.ob() + threadIdx.x] += dt * accb;
 }
 
+// H = 64: the same on the fp32 matrix cores.  Per 32-row tile and slab X in {S, I}:
+//   gW tile-accumulate  dW[j][k] += sum_r dpre_X[r][j] * y_X[r][k]   (wave w owns rows j in [16w,16w+16),
+//                        4 accumulator tiles kept in registers across ALL tiles of the workgroup)
+//   g_Y = dpre_X W       (mfma_tile with W staged transposed), written over the y tile, then
+//   a_X += dt * g_Y      in the coalesced row layout.
+__global__ __launch_bounds__(256) void k_bwd_mlp64(const float* __restrict__ dpre, const float* __restrict__ Ysol,
+                                                   const float* __restrict__ W, float dt, float* __restrict__ a,
+                                                   long rows, float* __restrict__ part_all) {
+    __shared__ __attribute__((aligned(16))) float WlT[64 * TS];
+    __shared__ __attribute__((aligned(16))) float Dt[2][TILE_ROWS * TS];
+    __shared__ __attribute__((aligned(16))) float Yt[2][TILE_ROWS * TS];
+    const PartLayout L{64};
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
+    const int i = lane & 15, kq = lane >> 4;
+    load_W_to_lds<true>(W, WlT);
+    const size_t slab = (size_t)rows * 64;
+    const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
+    f32x4 accW[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) accW[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
+    const long ntiles = (rows + TILE_ROWS - 1) / TILE_ROWS;
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        long r[2]; bool ok[2]; size_t off[2];
+        __syncthreads();                                   // previous tile fully consumed (and W staged)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            r[p] = t * TILE_ROWS + lr[p];
+            ok[p] = r[p] < rows;
+            off[p] = (size_t)r[p] * 64 + 4 * sub;
+#pragma unroll
+            for (int X = 0; X < 2; ++X) {
+                *reinterpret_cast<float4*>(&Dt[X][lr[p] * TS + 4 * sub]) = ok[p] ? ld4g(dpre + X * slab + off[p]) : zero4();
+                *reinterpret_cast<float4*>(&Yt[X][lr[p] * TS + 4 * sub]) = ok[p] ? ld4g(Ysol + X * slab + off[p]) : zero4();
+            }
+        }
+        __syncthreads();
+        // ---- gW: A[i = j][k' = r] = dpre[r][16w + i],  B[k' = r][n = k] = y[r][16kt + n]
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const int rr = 4 * s8 + kq;
+                const float av = Dt[X][rr * TS + 16 * w + i];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    accW[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Yt[X][rr * TS + 16 * kt + i], accW[kt], 0, 0, 0);
+            }
+        }
+        if (threadIdx.x < 64) {
+            float sacc = 0.f;
+            for (int rr = 0; rr < TILE_ROWS; ++rr) sacc += Dt[0][rr * TS + threadIdx.x] + Dt[1][rr * TS + threadIdx.x];
+            accb += sacc;
+        }
+        __syncthreads();                                   // y tiles are dead: overwrite them with g_Y
+        mfma_tile<false>(Dt[0], WlT, Yt[0], 0.f, w, lane);
+        mfma_tile<false>(Dt[1], WlT, Yt[1], 0.f, w, lane);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (!ok[p]) continue;
+#pragma unroll
+            for (int X = 0; X < 2; ++X) {
+                const float4 gy = *reinterpret_cast<const float4*>(&Yt[X][lr[p] * TS + 4 * sub]);
+                float4 av = ld4g(a + X * slab + off[p]);
+                av.x += dt * gy.x; av.y += dt * gy.y; av.z += dt * gy.z; av.w += dt * gy.w;
+                st4g(a + X * slab + off[p], av);
+            }
+        }
+    }
+    // C/D layout: column = lane & 15 -> k = 16 kt + i ; row = 4 (lane >> 4) + reg -> j = 16 w + 4 kq + reg
+    float* part = part_all + (size_t)blockIdx.x * L.total();
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            part[L.oW() + (16 * w + 4 * kq + reg) * 64 + 16 * kt + i] += dt * accW[kt][reg];
+    if (threadIdx.x < 64) part[L.ob() + threadIdx.x] += dt * accb;
+}
+
 // --------------------------------------------------------------------------- encoder backward
 template <int LPR>
 __global__ __launch_bounds__(256) void k_enc_bwd(const float* __restrict__ a, const float* __restrict__ sol0,
@@ -399,7 +480,8 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         const int s = slot_of(gi);
         if (s < 0) return 0;
         const size_t lds = (size_t)rpw * (4 * H + 9) * sizeof(float);
-        BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_head_bwd<LPR>, dim3(BWD_NWG), dim3(256), lds, st, sol + (size_t)gi * 4 * slab,
+        const int hgrid = (int)std::min<long>(BWD_NWG, std::max<long>(1, (rows + rpw - 1) / rpw));
+        BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_head_bwd<LPR>, dim3(hgrid), dim3(256), lds, st, sol + (size_t)gi * 4 * slab,
                                              (long)rows, H, gS + (size_t)s * rows, gI + (size_t)s * rows, gR + (size_t)s * rows,
                                              p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, a, part));
         GN_LAUNCH_CHECK();
@@ -417,12 +499,18 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_bwd_gather<LPR>, ggrid, dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, H, a,
                                              Z, q, beta, gamma, dpre));
         GN_LAUNCH_CHECK();
-        BWD_DISPATCH(lpr, {
-            if (mlp_lds > 64 * 1024)
-                GN_HIP(hipFuncSetAttribute((const void*)k_bwd_mlp<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds));
-            hipLaunchKernelGGL(k_bwd_mlp<LPR>, dim3(BWD_NWG), dim3(256), mlp_lds, st, dpre, yi, p->odefunc_linear_weight, dt, a,
-                               (long)rows, H, part);
-        });
+        if (H == 64) {
+            const int grid64 = (int)std::min<long>(BWD_NWG, std::max<long>(1, (rows + TILE_ROWS - 1) / TILE_ROWS));
+            hipLaunchKernelGGL(k_bwd_mlp64, dim3(grid64), dim3(256), 0, st, dpre, yi, p->odefunc_linear_weight, dt, a, (long)rows,
+                               part);
+        } else {
+            BWD_DISPATCH(lpr, {
+                if (mlp_lds > 64 * 1024)
+                    GN_HIP(hipFuncSetAttribute((const void*)k_bwd_mlp<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds));
+                hipLaunchKernelGGL(k_bwd_mlp<LPR>, dim3(BWD_NWG), dim3(256), mlp_lds, st, dpre, yi, p->odefunc_linear_weight, dt,
+                                   a, (long)rows, H, part);
+            });
+        }
         GN_LAUNCH_CHECK();
         if (int e = head(i - 1)) return e;
     }

@@ -1,7 +1,7 @@
-// GN-ODE hot path for MI355X (gfx950): node MLP, CSR pull-gather, SIR derivative,
-// Euler/RK4 update and fused read-out.  Hand-written for CDNA4: 64-lane
-// wavefronts, fp32 MFMA for the H=64 node MLP, one sub-wave lane group per node
-// row with 16-byte lane accesses (a 256-B row per 16 lanes at H=64).
+// GN-ODE hot path for MI355X (gfx950): C-ABI host code (graph handle, RHS, forward) and the
+// generic-H kernels (any H % 4 == 0): node MLP, CSR pull-gather, SIR derivative, Euler/RK4
+// update and fused read-out, one sub-wave lane group of H/4 lanes per node row with 16-byte
+// lane accesses.  H = 64 runs the fused MFMA kernels of gnode_h64.hip.
 //
 // Reference semantics restated (file:line into the reference tree):
 //   ODEfunc.forward      ode_nn_ngraph_sim.py:58-96   (multi: ode_nn_ngraphs.py:54-83)
@@ -16,8 +16,6 @@
 #include "gnode_h64.h"
 #include <algorithm>
 #include <cstdlib>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // --------------------------------------------------------------------------- error state
 static thread_local char g_err[512] = "";
@@ -191,67 +189,6 @@ __global__ __launch_bounds__(256) void k_mlp_generic(const float* __restrict__ X
     }
     st4(Z + (size_t)r * H + 4 * sub,
         make_float4(gn_sigmoid(acc.x), gn_sigmoid(acc.y), gn_sigmoid(acc.z), gn_sigmoid(acc.w)));
-}
-
-// H = 64 path on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
-// One wave = a 32-row tile; A = X tile (through LDS so the global read is a
-// coalesced 16 B/lane stream), B = W^T fragments held in registers for the whole
-// kernel.  k is visited in the order kappa(q,m,h) = 8q + 4h + m so that each
-// lane's A and B fragments are one 16-byte LDS / global read per q.
-#define MLP_LDS_STRIDE 68  // floats; 272 B rows keep ds_read_b128 conflict-free
-__global__ __launch_bounds__(256) void k_mlp_mfma64(const float* __restrict__ X, const float* __restrict__ W,
-                                                    const float* __restrict__ bias, float* __restrict__ Z,
-                                                    long nrows) {
-    __shared__ float lds[4][32 * MLP_LDS_STRIDE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 31, h = lane >> 5;
-    float4 wf[2][8];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) wf[t][q] = ld4(W + (size_t)(32 * t + i) * 64 + 8 * q + 4 * h);
-    const float bias0 = bias[i], bias1 = bias[32 + i];
-    float* tile = lds[wave];
-    const long ntiles = (nrows + 31) / 32;
-    for (long tix = (long)blockIdx.x * 4 + wave; tix < ntiles; tix += (long)gridDim.x * 4) {
-        const long row0 = tix * 32;
-        {   // coalesced stage: 4 rows x 256 B per wave instruction
-            const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const long rr = row0 + 4 * p + g;
-                float4 v = rr < nrows ? ld4(X + (size_t)rr * 64 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                st4(tile + (4 * p + g) * MLP_LDS_STRIDE + 4 * c, v);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = bias0; acc1[r] = bias1; }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 a = ld4(tile + i * MLP_LDS_STRIDE + 8 * q + 4 * h);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wf[0][q].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wf[1][q].x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wf[0][q].y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wf[1][q].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wf[0][q].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wf[1][q].z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wf[0][q].w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wf[1][q].w, acc1, 0, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // C/D layout: column = lane&31 (feature), row = (r&3) + 8*(r>>2) + 4*h
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (rr < nrows) {
-                Z[(size_t)rr * 64 + i] = gn_sigmoid(acc0[r]);
-                Z[(size_t)rr * 64 + 32 + i] = gn_sigmoid(acc1[r]);
-            }
-        }
-    }
 }
 
 // --------------------------------------------------------------------------- K2: gather + SIR derivative (+ Euler update + read-out)

@@ -34,7 +34,7 @@ __device__ __forceinline__ uint32_t philox_word0(uint32_t c0, uint32_t c1, uint3
 // --------------------------------------------------------------------------- production kernel
 // hist: uint32 [2][T][n]: [0] = infection events (t = 0 for seeds), [1] = recovery events.
 template <bool STATE_IN_LDS>
-__global__ __launch_bounds__(256) void k_sir_philox(const int* __restrict__ src, const int* __restrict__ dst, long nnz,
+__global__ __launch_bounds__(1024) void k_sir_philox(const int* __restrict__ src, const int* __restrict__ dst, long nnz,
                                                     int n, const int* __restrict__ seeds, int n_seeds,
                                                     unsigned long long thr_beta, unsigned long long thr_gamma,
                                                     long sims, long sim_offset, int T, uint32_t k0, uint32_t k1,
@@ -44,13 +44,14 @@ __global__ __launch_bounds__(256) void k_sir_philox(const int* __restrict__ src,
     uint8_t* flag = state + n;
     uint32_t* hinf = hist;
     uint32_t* hrec = hist + (size_t)T * n;
+    const int nthr = blockDim.x;                  // 256 for small graphs, 1024 when the LDS state allows one workgroup per CU
     for (long s = blockIdx.x; s < sims; s += gridDim.x) {
         const uint32_t sim = (uint32_t)(sim_offset + s);
-        for (int v = threadIdx.x; v < n; v += 256) { state[v] = ST_S; flag[v] = 0; }
+        for (int v = threadIdx.x; v < n; v += nthr) { state[v] = ST_S; flag[v] = 0; }
         __syncthreads();
-        for (int j = threadIdx.x; j < n_seeds; j += 256) state[seeds[j]] = ST_I;   // duplicates: same value
+        for (int j = threadIdx.x; j < n_seeds; j += nthr) state[seeds[j]] = ST_I;   // duplicates: same value
         __syncthreads();
-        for (int j = threadIdx.x; j < n_seeds; j += 256) {
+        for (int j = threadIdx.x; j < n_seeds; j += nthr) {
             // one infection event at t=0 per distinct seed node
             const int v = seeds[j];
             bool first = true;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void k_sir_philox(const int* __restrict__ src,
             if (first) atomicAdd(&hinf[v], 1u);
         }
         for (int it = 1; it < T; ++it) {
-            for (long e = threadIdx.x; e < nnz; e += 256) {
+            for (long e = threadIdx.x; e < nnz; e += nthr) {
                 const int u = src[e];
                 if (state[u] == ST_I) {
                     const int v = dst[e];
@@ -67,13 +68,13 @@ __global__ __launch_bounds__(256) void k_sir_philox(const int* __restrict__ src,
                         flag[v] = 1;
                 }
             }
-            for (int u = threadIdx.x; u < n; u += 256)
+            for (int u = threadIdx.x; u < n; u += nthr)
                 if (state[u] == ST_I &&
                     (unsigned long long)philox_word0((uint32_t)u, (uint32_t)it, sim, 1u, k0, k1) < thr_gamma)
                     flag[u] = 2;
             __syncthreads();
             int any = 0;
-            for (int v = threadIdx.x; v < n; v += 256) {
+            for (int v = threadIdx.x; v < n; v += nthr) {
                 const uint8_t f = flag[v];
                 if (f == 1) { state[v] = ST_I; atomicAdd(&hinf[(size_t)it * n + v], 1u); }
                 else if (f == 2) { state[v] = ST_R; atomicAdd(&hrec[(size_t)it * n + v], 1u); }
@@ -245,8 +246,11 @@ extern "C" int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, i
         if (lds <= kLdsStateLimit) {
             if (lds > 64 * 1024)
                 GN_HIP(hipFuncSetAttribute((const void*)k_sir_philox<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const int grid = (int)std::min<int64_t>(sims, 256 * 8);
-            hipLaunchKernelGGL(k_sir_philox<true>, dim3(grid), dim3(256), lds, st, src, g->col, (long)g->nnz, g->n, seeds,
+            // workgroups per CU by LDS; keep >= 16 waves per CU: big states get 1024-thread workgroups
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
+            const int threads = per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024);
+            const int grid = (int)std::min<int64_t>(sims, 256 * per_cu);
+            hipLaunchKernelGGL(k_sir_philox<true>, dim3(grid), dim3(threads), lds, st, src, g->col, (long)g->nnz, g->n, seeds,
                                n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (uint8_t*)nullptr);
         } else {
             const int grid = (int)std::min<int64_t>(sims, 2048);

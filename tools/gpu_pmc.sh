@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for HBM-side traffic of the step kernel (separate runs, kernel-trace only).
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU round: tests, bench, rocprof kernel trace.  Stops at the first step that hangs.
 set -o pipefail
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 mkdir -p $R/gpurun_out
 cd $R
 timeout -k 10 700 python -m pytest tests -m gpu -x -q -s > gpurun_out/test.log 2>&1; rc=$?

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 cd $R; mkdir -p gpurun_out
 run() { echo "== $*"; env "$@" timeout -k 10 300 python bench.py --steps ${STEPS:-4} --warmup 1 --no-cpu-baseline $BARGS 2>gpurun_out/sweep.err | python -c "
 import sys, json
