@@ -350,3 +350,38 @@ def test_sir_torch_statistics(dev):
     for a, b in ((S, So), (I, Io), (R, Ro)):
         dd = np.abs(a[0, 1:] - b[0, 1:]) / sims
         assert dd.max() < 0.05 and dd.mean() < 0.01
+
+
+# ------------------------------------------------------------------ BASELINE sizes (configs[3] shape)
+def test_full_size_short_horizon_vs_oracle(dev):
+    """75 000 nodes / 1 000 000 directed edges / H = 64, 2 samples: 4 Euler steps against the C oracle
+    (1e-5), then size-independent properties of the full 59-step run: S+I+R = 1, finite, and samples of a
+    batch never mix (bit-identical to a solo run)."""
+    import torch
+    import gnode_oracle as O
+    import oracle_c as OC
+    from gnode import ops
+    from gnode.graph import DeviceGraph
+    n, B, H = 75000, 2, 64
+    rp, ci, _ = O.er_graph(n, 500000, seed=0)
+    assert ci.shape[0] == 1000000
+    P = O.init_params(H, seed=0)
+    x = O.make_samples(n, B, H, seed=11)
+    g = DeviceGraph(rp, ci)
+    xt = torch.from_numpy(x).to(dev)
+    dts4 = ops.step_sizes(ops.time_grid(2.5, 0.5))
+    S, I, R, _ = ops.forward(g, xt.reshape(B * n, 3 + H), _tp(P, dev), dts4)
+    want = OC.forward_euler(rp, ci, n, x, P, dts4)
+    for got, w in zip((S, I, R), want):
+        assert _rel(got.cpu().numpy(), w[..., 0]) <= RTOL
+    dts = ops.step_sizes(ops.time_grid(30, 0.5))
+    S, I, R, _ = ops.forward(g, xt.reshape(B * n, 3 + H), _tp(P, dev), dts)
+    tot = S + I + R
+    assert bool(torch.isfinite(tot).all()) and float((tot - 1).abs().max()) < 1e-5
+    S1, I1, _, _ = ops.forward(g, xt[1].contiguous(), _tp(P, dev), dts)
+    assert torch.equal(S[:, n:], S1) and torch.equal(I[:, n:], I1)
+    # the trajectory-saving path (Y_R carried in full) agrees with the inference path (projected R)
+    S2, I2, R2, sol = ops.forward(g, xt[:1].reshape(n, 3 + H), _tp(P, dev), dts[:6], want_sol=True)
+    S3, I3, R3, _ = ops.forward(g, xt[:1].reshape(n, 3 + H), _tp(P, dev), dts[:6])
+    for u, v in ((S2, S3), (I2, I3), (R2, R3)):
+        assert _rel(u.cpu().numpy(), v.cpu().numpy()) <= 2e-6

@@ -1,0 +1,66 @@
+"""CPU: host-side logic of the drop-in layer that needs no GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_time_grid_and_subsample_rows():
+    from gnode import ops
+    g = ops.time_grid(20, 0.5)
+    assert g.dtype == np.float64 and g.shape == (40,) and g[-1] == 19.5          # ode_nn_ngraph_sim.py:110
+    dts = ops.step_sizes(g)
+    assert dts.dtype == np.float32 and dts.shape == (39,) and np.all(dts == np.float32(0.5))
+    assert ops.subsample_rows(20, 0.5).tolist() == list(range(0, 40, 2))         # ode_nn.py:257-259
+    assert ops.subsample_rows(3, 0.3).tolist() == [int(i / 0.3) for i in range(3)]
+    # non-dyadic step: fp32(dt_k) of the float64 grid differences, as torch would apply them
+    d = ops.step_sizes(ops.time_grid(1, 0.1))
+    assert d.shape == (9,) and np.all(np.abs(d - 0.1) < 1e-7)
+
+
+def test_sample_tensor_and_splits():
+    from gnode.trainer import sample_tensor, split_indices
+    x = sample_tensor(10, 8, [2, 7], 0.3, 0.15)
+    assert x.shape == (10, 11) and x.dtype == torch.float32
+    assert x[:, 0].sum() == 8 and x[[2, 7], 1].tolist() == [1.0, 1.0] and x[:, 2].sum() == 0
+    assert torch.all(x[:, 3] == np.float32(0.3)) and torch.all(x[:, 4] == np.float32(0.15)) and x[:, 5:].abs().sum() == 0
+    xm = sample_tensor(5, 8, [0], 0.2, 0.1, marker=3)
+    assert xm[0, 5] == 3 and xm[1:, 5].abs().sum() == 0                         # ode_nn_ngraphs.py:333
+    tr, va, te = split_indices(200, [0.6, 0.2, 0.2])
+    assert (len(tr), len(va), len(te)) == (120, 40, 40) and tr[0] == 0 and te[-1] == 199
+    tr, va, te = split_indices(6, None, {"train": [0, 2], "val": [5], "test": [1, 3, 4]})
+    assert (tr, va, te) == ([0, 2], [5], [1, 3, 4])
+
+
+def test_label_paths_and_csv(tmp_path):
+    from gnode.trainer import label_paths, csv_trials
+    ps = label_paths("./real_graphs/karate", "./multi-graph-1/Experiments-seed2-karate", [25, 18])
+    assert ps[0] == "./multi-graph-1/Experiments-seed2-karate/karate-S-25-18.pkl"   # ode_nn_ngraph_sim.py:191
+    f = str(tmp_path / "Metrics")
+    csv_trials(f, ["a", "b"], [1, 2]); csv_trials(f, ["a", "b"], [3, 4])
+    assert open(f).read().splitlines() == ["a,b", "1,2", "3,4"]
+
+
+def test_concat_csr_matches_block_diag():
+    import scipy.sparse as sp
+    import gnode_oracle as O
+    from gnode.graph import concat_csr, csr_arrays
+    gs = [O.er_graph(n, m, seed=n)[:2] for n, m in ((7, 9), (12, 20), (5, 4))]
+    rp, ci = concat_csr([gs[1], gs[0], gs[1], gs[2]])
+    mats = [sp.csr_matrix((np.ones(c.shape[0]), c, r), shape=(len(r) - 1,) * 2) for r, c in gs]
+    bd = sp.block_diag([mats[1], mats[0], mats[1], mats[2]]).tocsr()
+    bd.sort_indices()
+    assert np.array_equal(rp, bd.indptr) and np.array_equal(ci, bd.indices)
+    r2, c2 = csr_arrays(bd)
+    assert np.array_equal(r2, rp) and np.array_equal(c2, ci)
+    orp, oci, _ = O.concat_csr(gs, [1, 0, 1, 2])
+    assert np.array_equal(orp, rp) and np.array_equal(oci, ci)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from gnode import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.GnodeError, match="no CPU fallback"):
+        _lib.load()
