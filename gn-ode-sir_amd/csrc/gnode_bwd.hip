@@ -505,8 +505,11 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                                part);
         } else {
             BWD_DISPATCH(lpr, {
-                if (mlp_lds > 64 * 1024)
+                static bool attr_set = false;      // once per instantiation, never inside a stream capture
+                if (mlp_lds > 64 * 1024 && !attr_set) {
                     GN_HIP(hipFuncSetAttribute((const void*)k_bwd_mlp<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds));
+                    attr_set = true;
+                }
                 hipLaunchKernelGGL(k_bwd_mlp<LPR>, dim3(BWD_NWG), dim3(256), mlp_lds, st, dpre, yi, p->odefunc_linear_weight, dt,
                                    a, (long)rows, H, part);
             });

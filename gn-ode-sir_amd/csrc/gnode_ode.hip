@@ -307,6 +307,16 @@ __global__ __launch_bounds__(256) void k_lincomb(float* __restrict__ out, const 
     }
 }
 
+// sol[g][3rd slab] = sol[0][3rd slab] for g = 1 .. G-1: the beta-gamma slab rides along unchanged
+// (its derivative is 0, ode_nn_ngraph_sim.py:96); one launch instead of one copy per step.
+__global__ __launch_bounds__(256) void k_fill_bg(float* __restrict__ sol, size_t slab4, int G) {
+    const float* src = sol + 3 * slab4 * 4;                  // slab4 = floats per slab / 4
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < slab4; i += (size_t)gridDim.x * 256) {
+        const float4 v = ld4(src + 4 * i);
+        for (int g = 1; g < G; ++g) st4(sol + ((size_t)g * 4 + 3) * slab4 * 4 + 4 * i, v);
+    }
+}
+
 // --------------------------------------------------------------------------- host side
 static int lpr_for(int H) {
     int need = H / 4, l = 1;
@@ -344,8 +354,11 @@ static int launch_mlp(const float* X, const float* W, const float* b, float* Z, 
         const int rpw = 256 / lpr;
         const size_t lds = ((size_t)H * H + (size_t)rpw * H) * sizeof(float);
         DISPATCH_LPR(lpr, {
-            if (lds > 64 * 1024)
+            static bool attr_set = false;          // once per instantiation, never inside a stream capture
+            if (lds > 64 * 1024 && !attr_set) {
                 GN_HIP(hipFuncSetAttribute((const void*)k_mlp_generic<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
             hipLaunchKernelGGL(k_mlp_generic<LPR>, dim3((unsigned)((nrows + rpw - 1) / rpw)), dim3(256), lds, st, X, W, b, Z, nrows, H);
         });
     }
@@ -587,8 +600,11 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
                                            R + (size_t)slot * rows, st))
                     return e;
         }
-        if (sol_next)  // 4th slab rides along unchanged (derivative 0, ode_nn_ngraph_sim.py:96)
-            GN_HIP(hipMemcpyAsync(sol_next + 3 * slab, sol + 3 * slab, slab * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (sol && n_steps > 0) {
+        const size_t slab4 = slab / 4;
+        hipLaunchKernelGGL(k_fill_bg, dim3((unsigned)std::min<size_t>((slab4 + 255) / 256, 2048)), dim3(256), 0, st, sol, slab4, G);
+        GN_LAUNCH_CHECK();
     }
     return 0;
 }

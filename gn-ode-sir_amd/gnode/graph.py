@@ -51,6 +51,13 @@ class DeviceGraph:
     def from_scipy(cls, A):
         return cls(*csr_arrays(A))
 
+    # the device CSR is immutable: copies of a model share it, pickles rebuild it from the host arrays
+    def __deepcopy__(self, memo):
+        return self
+
+    def __reduce__(self):
+        return (DeviceGraph, (self.rowptr, self.col))
+
     def __del__(self):
         h = getattr(self, "handle", None)
         if h is not None and _lib._lib is not None:

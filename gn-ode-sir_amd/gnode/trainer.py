@@ -105,8 +105,15 @@ class Runner:
     rank back-propagates its share of the GLOBAL element-mean L1 (:234, :248-249) and the gradients
     are summed with one flat all-reduce."""
 
-    def __init__(self, model, lr, maxTime, deltaT, device, stack):
+    def __init__(self, model, lr, maxTime, deltaT, device, stack, use_graphs=None):
         self.model, self.device, self.stack = model, device, stack
+        # Launch-bound regime (the reference trains with batch_size 1 on small graphs): capture
+        # forward + loss + adjoint backward of each batch shape ONCE into a HIP graph and replay it.
+        # Single-graph batches only (the multi-graph forward reads its markers on the host).
+        if use_graphs is None:
+            use_graphs = os.environ.get("GNODE_TRAIN_GRAPHS", "1") != "0"
+        self.use_graphs = bool(use_graphs) and stack and torch.cuda.is_available() and str(device).startswith("cuda")
+        self._graphs = {}
         self.opt = torch.optim.Adam(model.parameters(), lr=lr)
         self.rows = ops.subsample_rows(maxTime, deltaT)
         self.rank, self.world = sharding.world_info()
@@ -138,6 +145,34 @@ class Runner:
         tgt = y[:, 1:, :]
         return (pred.to(tgt.dtype) - tgt).abs().sum()
 
+    def _graphed_backward(self, x, y, gcount):
+        """Replay (capturing on first use) forward + L1 + backward for this batch shape; returns the loss sum."""
+        key = (tuple(x.shape), tuple(y.shape), gcount)
+        ent = self._graphs.get(key)
+        if ent is None:
+            xs, ys = torch.zeros_like(x), torch.zeros_like(y)
+            xs.copy_(x); ys.copy_(y)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                 # warm-up: allocates .grad, sets kernel attributes
+                (self._loss_sum(xs, ys) / gcount).backward()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for p in self.model.parameters():
+                    if p.grad is not None:
+                        p.grad.zero_()
+                ls = self._loss_sum(xs, ys)
+                (ls / gcount).backward()
+                ls_out = ls.detach()
+            ent = (graph, xs, ys, ls_out)
+            self._graphs[key] = ent
+        graph, xs, ys, ls_out = ent
+        xs.copy_(x); ys.copy_(y)
+        graph.replay()
+        return ls_out
+
     def _global_sum(self, value):
         if self.world == 1:
             return value
@@ -150,11 +185,15 @@ class Runner:
         tot, items, t_fwd = 0.0, 0, 0.0
         T = ys[0].shape[1] if ys else 0
         for sel in self.batches(len(xs), batch_size, True, epoch):
-            self.opt.zero_grad()
+            self.opt.zero_grad(set_to_none=not self.use_graphs)
             gcount = sum(ys[j].shape[0] for j in sel) * (T - 1) * 3       # elements of the GLOBAL batch
             x, y = self._local(xs, ys, sel)
             lsum = 0.0
-            if x is not None:
+            if x is not None and self.use_graphs:
+                t0 = time.time()
+                lsum = float(self._graphed_backward(x, y, gcount))      # grads are (re)written by the replay
+                t_fwd += time.time() - t0
+            elif x is not None:
                 t0 = time.time()
                 ls = self._loss_sum(x, y)
                 t_fwd += time.time() - t0

@@ -16,6 +16,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+void oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+void oracle_set_threads(int n) { (void)n; }
+#endif
+
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 /* Z[r] = sigmoid(W X[r] + b): ode_nn_ngraph_sim.py:62-63 */

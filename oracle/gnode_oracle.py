@@ -379,6 +379,28 @@ def sir_philox(n, rowptr, col, seed_set, beta, gamma, sims, T, rng_seed, sim_off
 
 
 # --------------------------------------------------------------------------- reference-op-sequence port (cpu_baseline)
+def usable_cores():
+    """Host cores this process may actually use: the cgroup CPU quota when there is one (the GPU boxes
+    give 16 of 256 visible cores; 256 OpenMP threads on a 16-core quota run 10x SLOWER than 16), else
+    the affinity mask."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p_))
+        except Exception:
+            pass
+    return n
+
+
+
 def torch_port_forward(x, P, rowptr, col, maxTime, deltaT, n_steps=None, threads=None):
     """The reference's op sequence stated in PyTorch-CPU for the ``cpu_baseline``
     leg of bench.py (SURVEY 8d "Baseline A"): Linear + sigmoid, repeat-expanded
@@ -388,6 +410,7 @@ def torch_port_forward(x, P, rowptr, col, maxTime, deltaT, n_steps=None, threads
     workload).  Returns (S, I, R, seconds_in_euler_loop, steps_done)."""
     import time
     import torch
+    prev_threads = torch.get_num_threads()
     if threads:
         torch.set_num_threads(threads)
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=F32))
@@ -427,6 +450,7 @@ def torch_port_forward(x, P, rowptr, col, maxTime, deltaT, n_steps=None, threads
     ro = lambda Y: torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(Y, w3, b3)), w2, b2)
     out = torch.softmax(torch.cat((ro(sol[:, :q]), ro(sol[:, q:2 * q]), ro(sol[:, 2 * q:3 * q])), -1), dim=2)
     S, I, R = out.chunk(3, dim=-1)
+    torch.set_num_threads(prev_threads)       # a 256-thread pool makes every later tiny CPU op cost milliseconds
     return S.numpy(), I.numpy(), R.numpy(), secs, len(dts)
 
 

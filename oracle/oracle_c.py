@@ -20,6 +20,11 @@ def load():
         if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
             subprocess.run(["make", "-s", "-C", _HERE], check=True)
         _lib = C.CDLL(_SO)
+        try:                                   # respect the cgroup CPU share (gnode_oracle.usable_cores)
+            import gnode_oracle
+            _lib.oracle_set_threads(C.c_int(gnode_oracle.usable_cores()))
+        except Exception:
+            pass
     return _lib
 
 

@@ -91,3 +91,33 @@ def test_multi_graph_entry_point(tmp_path, monkeypatch, dev):
     assert main_multi(argv) == 0
     df = pd.read_csv("multi-graph-1/Experiments-seed2-ga+gb+gc/Metrics-trials-ga+gb+gc")
     assert len(df) == 1 and np.isfinite(df["test_loss"][0])
+
+
+def test_graph_replay_equals_eager(dev):
+    """HIP-graph replay of (forward + L1 + adjoint backward) gives bit-identical training to eager launches."""
+    import copy
+    import torch
+    import scipy.sparse as sp
+    import gnode_oracle as O
+    from gnode.ode_nn_ngraph_sim import ODEfunc, ODEBlock
+    from gnode.trainer import Runner, sample_tensor
+    n, H, maxTime = 90, 64, 6
+    rp, ci, _ = O.er_graph(n, 300, seed=2)
+    A = sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n))
+    rng = np.random.default_rng(0)
+    xs = [sample_tensor(n, H, sorted(rng.choice(n, 2, replace=False).tolist()), rng.uniform(0.1, 0.5), rng.uniform(0.1, 0.5))
+          for _ in range(7)]
+    ys = [torch.from_numpy(rng.dirichlet(np.ones(3), size=(n, maxTime))) for _ in range(7)]
+    torch.manual_seed(0)
+    base = ODEBlock(maxTime, 0.5, n, [0], H, ODEfunc(A, 0.2, 0.1, H, dev), dev).to(dev)
+    hist = []
+    for use_graphs in (False, True):
+        model = copy.deepcopy(base)
+        assert model.odefunc.graph is base.odefunc.graph
+        torch.manual_seed(123)
+        run = Runner(model, 1e-2, maxTime, 0.5, dev, stack=True, use_graphs=use_graphs)
+        run.seed = 5
+        losses = [run.train_epoch(xs, ys, 2, ep)[0] for ep in range(3)]       # batches of 2, last one of 1
+        hist.append((losses, [p.detach().clone() for p in model.parameters()]))
+    assert hist[0][0] == hist[1][0]
+    assert all(torch.equal(a, b) for a, b in zip(hist[0][1], hist[1][1]))

@@ -22,6 +22,7 @@ from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
 from gnode import ode_nn_ngraphs as multi
 
 dev = torch.device("cuda:0")
+torch.set_num_threads(O.usable_cores())
 
 
 def timed(fn, reps):
@@ -56,13 +57,27 @@ def single(name, n, m, B, H, maxTime, reps):
         opt.step()
 
     tf, tt = timed(fwd, reps), timed(train, max(2, reps // 2))
+    # the trainer's epoch loop (batch of B per optimiser step), eager launches vs HIP-graph replay
+    from gnode.trainer import Runner
+    xs = [x.cpu()[b] for b in range(B)] * 4
+    ys = [y.cpu()[b * n:(b + 1) * n] for b in range(B)] * 4
+    loop = {}
+    for mode in (False, True):
+        run = Runner(model, 1e-3, maxTime, 0.5, dev, stack=True, use_graphs=mode)
+        run.train_epoch(xs, ys, B, 0); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for ep in range(3):
+            run.train_epoch(xs, ys, B, ep)
+        torch.cuda.synchronize()
+        loop[mode] = (time.perf_counter() - t0) / (3 * 4)
     P = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if "ln." not in k}
     steps = len(ops.time_grid(maxTime, 0.5)) - 1
     cs = min(steps, 8)
-    _, _, _, secs, done = O.torch_port_forward(x_np, P, rp, ci, maxTime, 0.5, n_steps=cs, threads=os.cpu_count())
+    _, _, _, secs, done = O.torch_port_forward(x_np, P, rp, ci, maxTime, 0.5, n_steps=cs, threads=O.usable_cores())
     print(json.dumps({"case": name, "n": n, "nnz": int(ci.shape[0]), "B": B, "H": H, "euler_steps": steps,
-                      "forward_ms": tf * 1e3, "train_step_ms": tt * 1e3, "fwd_node_timesteps_per_s": B * n * steps / tf,
-                      "cpu_port_fwd_node_timesteps_per_s": B * n * done / secs, "cpu_threads": os.cpu_count()}))
+                      "forward_ms": tf * 1e3, "train_step_ms": tt * 1e3, "trainer_step_eager_ms": loop[False] * 1e3,
+                      "trainer_step_graph_ms": loop[True] * 1e3, "fwd_node_timesteps_per_s": B * n * steps / tf,
+                      "cpu_port_fwd_node_timesteps_per_s": B * n * done / secs, "cpu_threads": O.usable_cores()}))
 
 
 def multigraph(reps):

@@ -40,7 +40,7 @@ def main():
         infected_frac = float(1.0 - cnt[0, T - 1].float().mean().item() / sims)
         print(json.dumps({"case": name, "n": n, "nnz": int(ci.shape[0]), "sims": sims, "T": T, "gpu_s": dt,
                           "gpu_traj_steps_per_s": sims * (T - 1) / dt, "gpu_edge_visits_per_s": sims * (T - 1) * ci.shape[0] / dt,
-                          "cpu_port_traj_steps_per_s": csims * (T - 1) / cdt, "cpu_threads": os.cpu_count(),
+                          "cpu_port_traj_steps_per_s": csims * (T - 1) / cdt, "cpu_threads": O.usable_cores(),
                           "bit_exact_vs_oracle": ok, "final_attack_rate": infected_frac}))
 
 

@@ -9,6 +9,7 @@ for l in sys.stdin:
         d=json.loads(l); r=d['roofline']
         print('value %.4e  ms/step %.2f  step_us %.1f  mlp_us %.1f  frac %.3f chunk %s' % (d['value'], d['ms_per_step'], r['avg_launch_us'], r['node_mlp_avg_launch_us'], r['frac'], d['config']['samples_per_launch']))
 "; }
-for i in 1 2; do
-run GNODE_WGS_PER_CU=4
-done
+run GNODE_BENCH_OUT=all
+run GNODE_BENCH_OUT=sub
+run GNODE_BENCH_OUT=last
+run GNODE_BENCH_OUT=all GNODE_FUSE=0
