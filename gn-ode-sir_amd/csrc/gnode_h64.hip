@@ -118,7 +118,7 @@ __device__ __forceinline__ void readout64(float4 yS, float4 yI, float4 yR, const
     pS = eS * inv; pI = eI * inv; pR = eR * inv;
 }
 
-template <bool FUSE, bool NT, bool PRJ>
+template <bool FUSE, bool NT, bool PRJ, int XQ>
 __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                 long rows, int tiles_per_sample, long total_tiles,
                                                 float* __restrict__ Y, const float* __restrict__ ZI,
@@ -139,7 +139,14 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
 
     const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
 
-    for (long t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    // Tile walk.  XQ > 1: the tile range is cut into XQ contiguous queues (with 8 samples per launch a queue
+    // is one sample) and workgroup i serves queue i % XQ.  Workgroups are dealt round-robin over the 8 XCDs,
+    // so queue q is gathered through ONE XCD's L2: a sample's Z_I table competes for 4 MB instead of being
+    // spread over all eight L2s.  Placement only affects speed: every tile is visited exactly once either way.
+    const int xq = (XQ > 1 && gridDim.x % XQ == 0 && total_tiles >= 4 * XQ) ? XQ : 1;
+    const int q = blockIdx.x % xq;
+    const long q_lo = total_tiles * q / xq, q_hi = total_tiles * (q + 1) / xq;
+    for (long t = q_lo + blockIdx.x / xq; t < q_hi; t += gridDim.x / xq) {
         const long b = t / tiles_per_sample;
         const int tile = (int)(t - b * tiles_per_sample);
         const long base = b * n;
@@ -285,11 +292,13 @@ int gn_launch_step64(const gnode_graph_s* g, long rows, float* Y, const float* Z
     const int grid = (int)(k > 0 ? std::min<long>(total, (long)num_cus() * k) : total);
     static const bool nt = [] { const char* e = getenv("GNODE_NT"); return e ? e[0] != '0' : true; }();
     const bool prj = PR != nullptr;
-#define GN_STEP(F, N, P)                                                                                                    \
-    hipLaunchKernelGGL((k_step64<F, N, P>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, \
-                       ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,           \
+    static const bool xq8 = [] { const char* e = getenv("GNODE_XQ"); return e ? e[0] != '0' : true; }();
+#define GN_STEP(F, N, P, Q)                                                                                                    \
+    hipLaunchKernelGGL((k_step64<F, N, P, Q>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, \
+                       ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,              \
                        p->linearS2_bias, PR, out)
-#define GN_STEP_P(F, N) do { if (prj) GN_STEP(F, N, true); else GN_STEP(F, N, false); } while (0)
+#define GN_STEP_P(F, N) do { if (prj) { if (xq8) GN_STEP(F, N, true, 8); else GN_STEP(F, N, true, 1); }                        \
+                             else { if (xq8) GN_STEP(F, N, false, 8); else GN_STEP(F, N, false, 1); } } while (0)
     if (fuse) { if (nt) GN_STEP_P(true, true); else GN_STEP_P(true, false); }
     else { if (nt) GN_STEP_P(false, true); else GN_STEP_P(false, false); }
 #undef GN_STEP_P

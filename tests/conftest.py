@@ -18,3 +18,19 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _fresh_library(request):
+    """GPU sessions run against the CURRENT sources: rebuild libgnode_hip.so if it is stale (hipcc is on
+    the GPU box too).  A failed build fails the session loudly; there is no fallback path to fall back to."""
+    if request.config.getoption("-m") and "not gpu" in request.config.getoption("-m"):
+        return
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return
+    except Exception:
+        return
+    from gnode.build import build_lib
+    build_lib()
