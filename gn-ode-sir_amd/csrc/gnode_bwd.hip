@@ -22,7 +22,7 @@
 #include "gnode_mfma64.h"
 #include <algorithm>
 
-#define BWD_NWG 512
+#define BWD_NWG 768     // 3 workgroups per CU (52 KB of LDS each) on 256 CUs
 
 __device__ __forceinline__ float4 ld4b(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4b(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -275,14 +275,86 @@ __global__ __launch_bounds__(256) void k_bwd_mlp(const float* __restrict__ dpre,
     if (threadIdx.x < H) part[L.ob() + threadIdx.x] += dt * accb;
 }
 
-// H = 64: the same on the fp32 matrix cores.  Per 32-row tile and slab X in {S, I}:
+// --------------------------------------------------------------------------- H = 64 fused backward step
+// Per 32-row tile and slab X in {S, I}, on the fp32 matrix cores:
 //   gW tile-accumulate  dW[j][k] += sum_r dpre_X[r][j] * y_X[r][k]   (wave w owns rows j in [16w,16w+16),
 //                        4 accumulator tiles kept in registers across ALL tiles of the workgroup)
 //   g_Y = dpre_X W       (mfma_tile with W staged transposed), written over the y tile, then
 //   a_X += dt * g_Y      in the coalesced row layout.
-__global__ __launch_bounds__(256) void k_bwd_mlp64(const float* __restrict__ dpre, const float* __restrict__ Ysol,
-                                                   const float* __restrict__ W, float dt, float* __restrict__ a,
-                                                   long rows, float* __restrict__ part_all) {
+// Z = sigmoid(y_i W^T + b) for the S and I slabs (same MFMA tile engine as the forward) with the
+// S-slab epilogue also producing q = beta (a_I - a_S) * Z_S, the operand of the transposed gather.
+__global__ __launch_bounds__(256) void k_mlp64_q(const float* __restrict__ X, const float* __restrict__ W,
+                                                 const float* __restrict__ bias, float* __restrict__ Z,
+                                                 const float* __restrict__ a, const float* __restrict__ beta,
+                                                 float* __restrict__ q, long rows) {
+    __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
+    __shared__ __attribute__((aligned(16))) float T[TILE_ROWS * TS];
+    __shared__ __attribute__((aligned(16))) float T2[TILE_ROWS * TS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
+    load_W_to_lds<false>(W, Wl);
+    const float bias_l = bias[16 * w + (lane & 15)];
+    const long nrows = 2 * rows, ntiles = (nrows + TILE_ROWS - 1) / TILE_ROWS;
+    const size_t slab = (size_t)rows * 64;
+    const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        long r[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            r[p] = t * TILE_ROWS + lr[p];
+            *reinterpret_cast<float4*>(T + lr[p] * TS + 4 * sub) = r[p] < nrows ? ld4g(X + (size_t)r[p] * 64 + 4 * sub) : zero4();
+        }
+        __syncthreads();
+        mfma_tile<true>(T, Wl, T2, bias_l, w, lane);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (r[p] >= nrows) continue;
+            const float4 z = *reinterpret_cast<const float4*>(T2 + lr[p] * TS + 4 * sub);
+            const size_t off = (size_t)r[p] * 64 + 4 * sub;
+            st4g(Z + off, z);
+            if (r[p] < rows) {                                   // S slab: q rides along
+                const float bt = beta[r[p]];
+                const float4 aS = ld4g(a + off), aI = ld4g(a + slab + off);
+                st4g(q + off, make_float4(bt * (aI.x - aS.x) * z.x, bt * (aI.y - aS.y) * z.y, bt * (aI.z - aS.z) * z.z,
+                                          bt * (aI.w - aS.w) * z.w));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// two tables gathered through the same neighbour list (AI = A Z_I, Gq = A q), ascending column order
+__device__ __forceinline__ void gather2_row64(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                              const float* __restrict__ T0, const float* __restrict__ T1, int node,
+                                              bool valid, int sub, float4& acc0, float4& acc1) {
+    acc0 = zero4(); acc1 = zero4();
+    int start = 0, end = 0;
+    if (valid) { start = rowptr[node]; end = rowptr[node + 1]; }
+    for (int e0 = start; e0 < end; e0 += 16) {
+        const int cnt = min(16, end - e0);
+        const int mine = (sub < cnt) ? col[e0 + sub] : 0;
+#define GN_G2(J)                                                                                   \
+        if (J < cnt) {                                                                             \
+            const size_t o0 = (size_t)row_bcast<J>(mine) * 64 + 4 * sub;                           \
+            float4 u0 = ld4g(T0 + o0), v0 = ld4g(T1 + o0), u1 = zero4(), v1 = u1;                  \
+            if (J + 1 < cnt) { const size_t o1 = (size_t)row_bcast<J + 1>(mine) * 64 + 4 * sub; u1 = ld4g(T0 + o1); v1 = ld4g(T1 + o1); } \
+            acc0.x += u0.x; acc0.y += u0.y; acc0.z += u0.z; acc0.w += u0.w;                        \
+            acc1.x += v0.x; acc1.y += v0.y; acc1.z += v0.z; acc1.w += v0.w;                        \
+            acc0.x += u1.x; acc0.y += u1.y; acc0.z += u1.z; acc0.w += u1.w;                        \
+            acc1.x += v1.x; acc1.y += v1.y; acc1.z += v1.z; acc1.w += v1.w;                        \
+        }
+        GN_G2(0) GN_G2(2) GN_G2(4) GN_G2(6) GN_G2(8) GN_G2(10) GN_G2(12) GN_G2(14)
+#undef GN_G2
+    }
+}
+
+// One launch per backward interval: both gathers, dpre, gW/gb accumulation and a += dt dpre W, tile by tile.
+__global__ __launch_bounds__(256) void k_bwd_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+                                                    long rows, int tiles_per_sample, long total_tiles,
+                                                    const float* __restrict__ Z, const float* __restrict__ q,
+                                                    const float* __restrict__ Ysol, const float* __restrict__ W,
+                                                    const float* __restrict__ beta, const float* __restrict__ gamma,
+                                                    float dt, float* __restrict__ a, float* __restrict__ part_all) {
     __shared__ __attribute__((aligned(16))) float WlT[64 * TS];
     __shared__ __attribute__((aligned(16))) float Dt[2][TILE_ROWS * TS];
     __shared__ __attribute__((aligned(16))) float Yt[2][TILE_ROWS * TS];
@@ -291,28 +363,47 @@ __global__ __launch_bounds__(256) void k_bwd_mlp64(const float* __restrict__ dpr
     const int i = lane & 15, kq = lane >> 4;
     load_W_to_lds<true>(W, WlT);
     const size_t slab = (size_t)rows * 64;
+    const float* ZS = Z; const float* ZI = Z + slab;
     const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
     f32x4 accW[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) accW[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float accb = 0.f;
-    const long ntiles = (rows + TILE_ROWS - 1) / TILE_ROWS;
-    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        long r[2]; bool ok[2]; size_t off[2];
+    for (long t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const long b = t / tiles_per_sample;
+        const int tile = (int)(t - b * tiles_per_sample);
+        const long base = b * n;
+        bool valid[2]; size_t off[2]; float4 aS[2], aI[2];
         __syncthreads();                                   // previous tile fully consumed (and W staged)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            r[p] = t * TILE_ROWS + lr[p];
-            ok[p] = r[p] < rows;
-            off[p] = (size_t)r[p] * 64 + 4 * sub;
-#pragma unroll
-            for (int X = 0; X < 2; ++X) {
-                *reinterpret_cast<float4*>(&Dt[X][lr[p] * TS + 4 * sub]) = ok[p] ? ld4g(dpre + X * slab + off[p]) : zero4();
-                *reinterpret_cast<float4*>(&Yt[X][lr[p] * TS + 4 * sub]) = ok[p] ? ld4g(Ysol + X * slab + off[p]) : zero4();
+            const int node = tile * TILE_ROWS + lr[p];
+            valid[p] = node < n;
+            off[p] = (size_t)(base + node) * 64 + 4 * sub;
+            float4 ai, gq;
+            gather2_row64(rowptr, col, ZI + (size_t)base * 64, q + (size_t)base * 64, node, valid[p], sub, ai, gq);
+            float4 dS = zero4(), dI = zero4();
+            aS[p] = zero4(); aI[p] = zero4();
+            if (valid[p]) {
+                const float bt = beta[base + node], gm = gamma[base + node];
+                aS[p] = ld4g(a + off[p]); aI[p] = ld4g(a + slab + off[p]);
+                const float4 aR = ld4g(a + 2 * slab + off[p]);
+                const float4 zs = ld4g(ZS + off[p]), zi = ld4g(ZI + off[p]);
+#define GN_DP(c)                                                               \
+                {                                                              \
+                    const float v = bt * (aI[p].c - aS[p].c);                  \
+                    dS.c = (v * ai.c) * (zs.c * (1.0f - zs.c));                \
+                    dI.c = (gq.c + gm * (aR.c - aI[p].c)) * (zi.c * (1.0f - zi.c)); \
+                }
+                GN_DP(x) GN_DP(y) GN_DP(z) GN_DP(w)
+#undef GN_DP
             }
+            *reinterpret_cast<float4*>(&Dt[0][lr[p] * TS + 4 * sub]) = dS;
+            *reinterpret_cast<float4*>(&Dt[1][lr[p] * TS + 4 * sub]) = dI;
+            *reinterpret_cast<float4*>(&Yt[0][lr[p] * TS + 4 * sub]) = valid[p] ? ld4g(Ysol + off[p]) : zero4();
+            *reinterpret_cast<float4*>(&Yt[1][lr[p] * TS + 4 * sub]) = valid[p] ? ld4g(Ysol + slab + off[p]) : zero4();
         }
         __syncthreads();
-        // ---- gW: A[i = j][k' = r] = dpre[r][16w + i],  B[k' = r][n = k] = y[r][16kt + n]
 #pragma unroll
         for (int X = 0; X < 2; ++X) {
 #pragma unroll
@@ -329,23 +420,20 @@ __global__ __launch_bounds__(256) void k_bwd_mlp64(const float* __restrict__ dpr
             for (int rr = 0; rr < TILE_ROWS; ++rr) sacc += Dt[0][rr * TS + threadIdx.x] + Dt[1][rr * TS + threadIdx.x];
             accb += sacc;
         }
-        __syncthreads();                                   // y tiles are dead: overwrite them with g_Y
+        __syncthreads();
         mfma_tile<false>(Dt[0], WlT, Yt[0], 0.f, w, lane);
         mfma_tile<false>(Dt[1], WlT, Yt[1], 0.f, w, lane);
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            if (!ok[p]) continue;
-#pragma unroll
-            for (int X = 0; X < 2; ++X) {
-                const float4 gy = *reinterpret_cast<const float4*>(&Yt[X][lr[p] * TS + 4 * sub]);
-                float4 av = ld4g(a + X * slab + off[p]);
-                av.x += dt * gy.x; av.y += dt * gy.y; av.z += dt * gy.z; av.w += dt * gy.w;
-                st4g(a + X * slab + off[p], av);
-            }
+            if (!valid[p]) continue;
+            const float4 gS = *reinterpret_cast<const float4*>(&Yt[0][lr[p] * TS + 4 * sub]);
+            const float4 gI = *reinterpret_cast<const float4*>(&Yt[1][lr[p] * TS + 4 * sub]);
+            aS[p].x += dt * gS.x; aS[p].y += dt * gS.y; aS[p].z += dt * gS.z; aS[p].w += dt * gS.w;
+            aI[p].x += dt * gI.x; aI[p].y += dt * gI.y; aI[p].z += dt * gI.z; aI[p].w += dt * gI.w;
+            st4g(a + off[p], aS[p]); st4g(a + slab + off[p], aI[p]);
         }
     }
-    // C/D layout: column = lane & 15 -> k = 16 kt + i ; row = 4 (lane >> 4) + reg -> j = 16 w + 4 kq + reg
     float* part = part_all + (size_t)blockIdx.x * L.total();
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
@@ -471,6 +559,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     GN_LAUNCH_CHECK();
 
     const int lpr = lpr_of(H), rpw = 256 / lpr;
+    int slots_used = 1;                                  // highest workgroup slot any launch wrote, for the final reduction
     auto slot_of = [&](int gi) -> int {
         if (!out_rows_host) return gi;
         for (int i = 0; i < n_out; ++i) if (out_rows_host[i] == gi) return i;
@@ -481,6 +570,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         if (s < 0) return 0;
         const size_t lds = (size_t)rpw * (4 * H + 9) * sizeof(float);
         const int hgrid = (int)std::min<long>(BWD_NWG, std::max<long>(1, (rows + rpw - 1) / rpw));
+        slots_used = std::max(slots_used, hgrid);
         BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_head_bwd<LPR>, dim3(hgrid), dim3(256), lds, st, sol + (size_t)gi * 4 * slab,
                                              (long)rows, H, gS + (size_t)s * rows, gI + (size_t)s * rows, gR + (size_t)s * rows,
                                              p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, a, part));
@@ -492,37 +582,47 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     for (int i = G - 1; i >= 1; --i) {
         const float* yi = sol + (size_t)i * 4 * slab;
         const float dt = dt_host[i - 1];
-        if (int e = gn_launch_mlp_any(yi, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
-        hipLaunchKernelGGL(k_bwd_q, dim3(2048), dim3(256), 0, st, a, Z, beta, q, (long)rows, H);
-        GN_LAUNCH_CHECK();
-        dim3 ggrid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)(rows / g->n));
-        BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_bwd_gather<LPR>, ggrid, dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, H, a,
-                                             Z, q, beta, gamma, dpre));
-        GN_LAUNCH_CHECK();
         if (H == 64) {
-            const int grid64 = (int)std::min<long>(BWD_NWG, std::max<long>(1, (rows + TILE_ROWS - 1) / TILE_ROWS));
-            hipLaunchKernelGGL(k_bwd_mlp64, dim3(grid64), dim3(256), 0, st, dpre, yi, p->odefunc_linear_weight, dt, a, (long)rows,
-                               part);
+            const long mt = (2 * rows + TILE_ROWS - 1) / TILE_ROWS;
+            hipLaunchKernelGGL(k_mlp64_q, dim3((unsigned)std::min<long>(mt, 1024)), dim3(256), 0, st, yi, p->odefunc_linear_weight,
+                               p->odefunc_linear_bias, Z, a, beta, q, (long)rows);
+            GN_LAUNCH_CHECK();
+            const int tps = (g->n + TILE_ROWS - 1) / TILE_ROWS;
+            const long total = (long)(rows / g->n) * tps;
+            slots_used = std::max(slots_used, (int)std::min<long>(BWD_NWG, total));
+            hipLaunchKernelGGL(k_bwd_step64, dim3((unsigned)std::min<long>(BWD_NWG, total)), dim3(256), 0, st, g->rowptr, g->col,
+                               g->n, (long)rows, tps, total, Z, q, yi, p->odefunc_linear_weight, beta, gamma, dt, a, part);
+            GN_LAUNCH_CHECK();
         } else {
+            if (int e = gn_launch_mlp_any(yi, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
+            hipLaunchKernelGGL(k_bwd_q, dim3(2048), dim3(256), 0, st, a, Z, beta, q, (long)rows, H);
+            GN_LAUNCH_CHECK();
+            dim3 ggrid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)(rows / g->n));
+            BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_bwd_gather<LPR>, ggrid, dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, H,
+                                                 a, Z, q, beta, gamma, dpre));
+            GN_LAUNCH_CHECK();
             BWD_DISPATCH(lpr, {
                 static bool attr_set = false;      // once per instantiation, never inside a stream capture
                 if (mlp_lds > 64 * 1024 && !attr_set) {
                     GN_HIP(hipFuncSetAttribute((const void*)k_bwd_mlp<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds));
                     attr_set = true;
                 }
+                slots_used = BWD_NWG;
                 hipLaunchKernelGGL(k_bwd_mlp<LPR>, dim3(BWD_NWG), dim3(256), mlp_lds, st, dpre, yi, p->odefunc_linear_weight, dt,
                                    a, (long)rows, H, part);
             });
+            GN_LAUNCH_CHECK();
         }
-        GN_LAUNCH_CHECK();
         if (int e = head(i - 1)) return e;
     }
     {
         const size_t lds = (size_t)rpw * 2 * H * sizeof(float);
-        BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_enc_bwd<LPR>, dim3(BWD_NWG), dim3(256), lds, st, a, sol, x, (long)rows, H, part));
+        const int egrid = (int)std::min<long>(BWD_NWG, std::max<long>(1, (rows + rpw - 1) / rpw));
+        slots_used = std::max(slots_used, egrid);
+        BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_enc_bwd<LPR>, dim3(egrid), dim3(256), lds, st, a, sol, x, (long)rows, H, part));
         GN_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((L.total() + 255) / 256), dim3(256), 0, st, part, BWD_NWG, L.total(), red);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((L.total() + 255) / 256), dim3(256), 0, st, part, slots_used, L.total(), red);
     GN_LAUNCH_CHECK();
     struct { float* dst; int off; int cnt; } outv[] = {
         {(float*)grads->odefunc_linear_weight, L.oW(), H * H}, {(float*)grads->odefunc_linear_bias, L.ob(), H},
