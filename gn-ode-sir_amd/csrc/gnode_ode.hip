@@ -429,8 +429,15 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
         delete g;
         return GNODE_ERR_HIP;
     }
-    GN_HIP(hipMemcpy(g->rowptr, rowptr_host, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
-    if (nnz) GN_HIP(hipMemcpy(g->col, col_host, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    hipError_t e3 = hipMemcpy(g->rowptr, rowptr_host, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice);
+    hipError_t e4 = nnz ? hipMemcpy(g->col, col_host, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice) : hipSuccess;
+    if (e3 != hipSuccess || e4 != hipSuccess) {
+        gnode_set_error("gnode_graph_create: hipMemcpy failed: %s", hipGetErrorString(e3 != hipSuccess ? e3 : e4));
+        (void)hipFree(g->rowptr);
+        (void)hipFree(g->col);
+        delete g;
+        return GNODE_ERR_HIP;
+    }
     *out = g;
     return 0;
 }

@@ -44,8 +44,15 @@ class DeviceGraph:
         self.n = int(self.rowptr.shape[0] - 1)
         self.nnz = int(self.col.shape[0])
         h = C.c_void_p()
+        import torch
+        self.device_index = torch.cuda.current_device() if torch.cuda.is_available() else -1   # the CSR lives on THIS GPU
         _lib.check(lib.gnode_graph_create(_lib.host_ptr(self.rowptr), _lib.host_ptr(self.col), self.n, self.nnz, C.byref(h)))
         self.handle = h
+
+    def check_device(self, tensor):
+        """One process drives one GPU: refuse tensors that live on another device than the graph."""
+        if tensor.is_cuda and tensor.device.index != self.device_index:
+            raise _lib.GnodeError(f"graph lives on cuda:{self.device_index}, tensor on {tensor.device}")
 
     @classmethod
     def from_scipy(cls, A):
@@ -59,7 +66,10 @@ class DeviceGraph:
         return (DeviceGraph, (self.rowptr, self.col))
 
     def __del__(self):
-        h = getattr(self, "handle", None)
-        if h is not None and _lib._lib is not None:
-            _lib._lib.gnode_graph_destroy(h)
-            self.handle = None
+        try:
+            h = getattr(self, "handle", None)
+            if h is not None and _lib is not None and _lib._lib is not None:
+                _lib._lib.gnode_graph_destroy(h)
+                self.handle = None
+        except Exception:       # interpreter shutdown: module globals may already be gone
+            pass

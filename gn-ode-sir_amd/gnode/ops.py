@@ -55,6 +55,7 @@ def rhs(graph: DeviceGraph, x: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -
     """ODEfunc.forward on x [4*rows, H] (ode_nn_ngraph_sim.py:58-96)."""
     lib = _lib.load()
     x = _f32c(x)
+    graph.check_device(x)
     rows4, H = x.shape
     if rows4 % 4:
         raise _lib.GnodeError("state must have 4 slabs")
@@ -71,6 +72,7 @@ def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray
     """ODEBlock.forward on x2d [rows, 3+H]; returns (S, I, R) each [n_out, rows] and sol or None."""
     lib = _lib.load()
     x2d = _f32c(x2d)
+    graph.check_device(x2d)
     rows, H = x2d.shape[0], x2d.shape[1] - 3
     dts = np.ascontiguousarray(dts, dtype=np.float32)
     n_steps = int(dts.shape[0])
