@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void k_bwd_gather(const int* __restrict__ rowp
                                                     long rows, int H, const float* __restrict__ a,
                                                     const float* __restrict__ Z, const float* __restrict__ q,
                                                     const float* __restrict__ beta, const float* __restrict__ gamma,
-                                                    float* __restrict__ dpre) {
+                                                    float* __restrict__ dpre, const int* __restrict__ hubidx,
+                                                    const float* __restrict__ AIhub, const float* __restrict__ GQhub, int n_hub) {
     const int sub = threadIdx.x % LPR;
     const int node = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (node >= n) return;
@@ -165,7 +166,12 @@ __global__ __launch_bounds__(256) void k_bwd_gather(const int* __restrict__ rowp
     const size_t slab = (size_t)rows * H, off = (size_t)r * H + 4 * sub;
     const float* ZI = Z + slab;
     float4 ai = z4(), gq = z4();
-    const int start = rowptr[node], end = rowptr[node + 1];
+    const int hub = hubidx ? hubidx[node] : -1;
+    if (hub >= 0 && active) {
+        ai = ld4b(AIhub + ((size_t)blockIdx.y * n_hub + hub) * H + 4 * sub);
+        gq = ld4b(GQhub + ((size_t)blockIdx.y * n_hub + hub) * H + 4 * sub);
+    }
+    const int start = hub >= 0 ? 0 : rowptr[node], end = hub >= 0 ? 0 : rowptr[node + 1];
     for (int e0 = start; e0 < end; e0 += LPR) {
         const int cnt = min(LPR, end - e0);
         const int mine = (sub < cnt) ? col[e0 + sub] : 0;
@@ -354,7 +360,9 @@ __global__ __launch_bounds__(256) void k_bwd_step64(const int* __restrict__ rowp
                                                     const float* __restrict__ Z, const float* __restrict__ q,
                                                     const float* __restrict__ Ysol, const float* __restrict__ W,
                                                     const float* __restrict__ beta, const float* __restrict__ gamma,
-                                                    float dt, float* __restrict__ a, float* __restrict__ part_all) {
+                                                    float dt, float* __restrict__ a, float* __restrict__ part_all,
+                                                    const int* __restrict__ hubidx, const float* __restrict__ AIhub,
+                                                    const float* __restrict__ GQhub, int n_hub) {
     __shared__ __attribute__((aligned(16))) float WlT[64 * TS];
     __shared__ __attribute__((aligned(16))) float Dt[2][TILE_ROWS * TS];
     __shared__ __attribute__((aligned(16))) float Yt[2][TILE_ROWS * TS];
@@ -381,7 +389,13 @@ __global__ __launch_bounds__(256) void k_bwd_step64(const int* __restrict__ rowp
             valid[p] = node < n;
             off[p] = (size_t)(base + node) * 64 + 4 * sub;
             float4 ai, gq;
-            gather2_row64(rowptr, col, ZI + (size_t)base * 64, q + (size_t)base * 64, node, valid[p], sub, ai, gq);
+            const int hub = (hubidx && valid[p]) ? hubidx[node] : -1;
+            if (hub >= 0) {
+                ai = ld4g(AIhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+                gq = ld4g(GQhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+            } else {
+                gather2_row64(rowptr, col, ZI + (size_t)base * 64, q + (size_t)base * 64, node, valid[p], sub, ai, gq);
+            }
             float4 dS = zero4(), dI = zero4();
             aS[p] = zero4(); aI[p] = zero4();
             if (valid[p]) {
@@ -590,16 +604,21 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
             const int tps = (g->n + TILE_ROWS - 1) / TILE_ROWS;
             const long total = (long)(rows / g->n) * tps;
             slots_used = std::max(slots_used, (int)std::min<long>(BWD_NWG, total));
+            const float *AIhub = nullptr, *GQhub = nullptr;
+            if (int e = gn_hub_gather(g, rows / g->n, 64, Z + slab, q, &AIhub, &GQhub, st)) return e;
             hipLaunchKernelGGL(k_bwd_step64, dim3((unsigned)std::min<long>(BWD_NWG, total)), dim3(256), 0, st, g->rowptr, g->col,
-                               g->n, (long)rows, tps, total, Z, q, yi, p->odefunc_linear_weight, beta, gamma, dt, a, part);
+                               g->n, (long)rows, tps, total, Z, q, yi, p->odefunc_linear_weight, beta, gamma, dt, a, part,
+                               g->hubidx, AIhub, GQhub, g->n_hub);
             GN_LAUNCH_CHECK();
         } else {
             if (int e = gn_launch_mlp_any(yi, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
             hipLaunchKernelGGL(k_bwd_q, dim3(2048), dim3(256), 0, st, a, Z, beta, q, (long)rows, H);
             GN_LAUNCH_CHECK();
             dim3 ggrid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)(rows / g->n));
+            const float *AIhub = nullptr, *GQhub = nullptr;
+            if (int e = gn_hub_gather(g, rows / g->n, H, Z + slab, q, &AIhub, &GQhub, st)) return e;
             BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_bwd_gather<LPR>, ggrid, dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, H,
-                                                 a, Z, q, beta, gamma, dpre));
+                                                 a, Z, q, beta, gamma, dpre, g->hubidx, AIhub, GQhub, g->n_hub));
             GN_LAUNCH_CHECK();
             BWD_DISPATCH(lpr, {
                 static bool attr_set = false;      // once per instantiation, never inside a stream capture

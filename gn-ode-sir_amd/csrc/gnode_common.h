@@ -12,7 +12,20 @@ struct gnode_graph_s {
     int32_t max_degree;
     int32_t* rowptr;  // device [n+1]
     int32_t* col;     // device [nnz]
+    // hub rows (gnode_hub.hip): rows longer than the hub threshold, cut into <= 32-edge segments
+    int32_t n_hub, n_seg;
+    int32_t* hubidx;        // device [n]: hub index of a row, -1 for ordinary rows (null when n_hub == 0)
+    int32_t* seg_lo;        // device [n_seg]: first CSR position of a segment
+    int32_t* seg_hi;        // device [n_seg]: one past its last
+    int32_t* hub_seg_ptr;   // device [n_hub+1]: segments of hub h are [ptr[h], ptr[h+1])
+    void* hub_scratch;      // device, grow-only: segment partials + hub sums for the largest batch seen
+    size_t hub_scratch_bytes;
 };
+
+int gn_hub_build(gnode_graph_s* g, const int32_t* rowptr_host);
+void gn_hub_free(gnode_graph_s* g);
+int gn_hub_gather(gnode_graph_s* g, long B, int H, const float* T0, const float* T1, const float** A0, const float** A1,
+                  hipStream_t st);
 
 void gnode_set_error(const char* fmt, ...);
 

@@ -8,7 +8,7 @@ struct Step64Out {
 };
 
 int gn_launch_mlp64(const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st);
-int gn_launch_step64(const gnode_graph_s* g, long rows, float* Y, const float* ZI, float* ZI_next, const float* W,
+int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, float* ZI_next, const float* W,
                      const float* bias, const float* beta, const float* gamma, float dt, const gnode_params* p,
                      float* PR /* [rows][4] projected R state, or null = carry Y_R */, Step64Out out, bool fuse,
                      hipStream_t st);

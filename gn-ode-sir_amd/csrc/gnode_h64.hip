@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
                                                 const float* __restrict__ gamma, float dt,
                                                 const float* __restrict__ w3, const float* __restrict__ b3,
                                                 const float* __restrict__ w2, const float* __restrict__ b2,
-                                                float* __restrict__ PR, Step64Out out) {
+                                                float* __restrict__ PR, Step64Out out,
+                                                const int* __restrict__ hubidx, const float* __restrict__ AIhub, int n_hub) {
     __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
     __shared__ __attribute__((aligned(16))) float T[TILE_ROWS * TS];
     __shared__ __attribute__((aligned(16))) float T2[TILE_ROWS * TS];
@@ -169,8 +170,13 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
         }
         // (measured: gathering the two rows in lockstep with 8 loads in flight per lane is 25 % SLOWER --
         //  the memory system is already at its request-rate limit)
-        ai[0] = gather_row64(rowptr, col, ZI + (size_t)base * 64, node[0], valid[0], sub);
-        ai[1] = gather_row64(rowptr, col, ZI + (size_t)base * 64, node[1], valid[1], sub);
+        // long rows ("hubs") were summed beforehand by the segment kernels of gnode_hub.hip
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int hub = (hubidx && valid[p]) ? hubidx[node[p]] : -1;
+            if (hub >= 0) ai[p] = ld4g(AIhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+            else ai[p] = gather_row64(rowptr, col, ZI + (size_t)base * 64, node[p], valid[p], sub);
+        }
         __syncthreads();
         // -------- P2: Z_S on the matrix cores
         mfma_tile<true>(T, Wl, T2, bias_l, w, lane);
@@ -281,11 +287,13 @@ int gn_launch_mlp64(const float* X, const float* W, const float* b, float* Z, lo
     return 0;
 }
 
-int gn_launch_step64(const gnode_graph_s* g, long rows, float* Y, const float* ZI, float* ZI_next, const float* W,
+int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, float* ZI_next, const float* W,
                      const float* bias, const float* beta, const float* gamma, float dt, const gnode_params* p,
                      float* PR, Step64Out out, bool fuse, hipStream_t st) {
     const int tps = (g->n + TILE_ROWS - 1) / TILE_ROWS;
     const long total = (long)(rows / g->n) * tps;
+    const float* AIhub = nullptr;
+    if (int e = gn_hub_gather(g, rows / g->n, 64, ZI, nullptr, &AIhub, nullptr, st)) return e;
     const int k = wgs_per_cu();
     // (measured: shrinking the grid so that every persistent workgroup gets the same number of tiles is 3 % SLOWER
     //  than filling all 4 x CUs slots and accepting a +-1 tile imbalance -- residency matters more)
@@ -296,7 +304,7 @@ int gn_launch_step64(const gnode_graph_s* g, long rows, float* Y, const float* Z
 #define GN_STEP(F, N, P, Q)                                                                                                    \
     hipLaunchKernelGGL((k_step64<F, N, P, Q>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, \
                        ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,              \
-                       p->linearS2_bias, PR, out)
+                       p->linearS2_bias, PR, out, g->hubidx, AIhub, g->n_hub)
 #define GN_STEP_P(F, N) do { if (prj) { if (xq8) GN_STEP(F, N, true, 8); else GN_STEP(F, N, true, 1); }                        \
                              else { if (xq8) GN_STEP(F, N, false, 8); else GN_STEP(F, N, false, 1); } } while (0)
     if (fuse) { if (nt) GN_STEP_P(true, true); else GN_STEP_P(true, false); }

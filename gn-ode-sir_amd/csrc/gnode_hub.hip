@@ -1,0 +1,208 @@
+// Hub rows: degree-skew handling for the CSR pull-gather (gfx950).
+//
+// A row gather is a chain of dependent memory batches (4 neighbour rows in flight per 16-lane
+// group, ~1-2 us each under load).  That is fine at degree ~13 (Erdos-Renyi) and terrible on the
+// graphs the reference actually ships: wiki-vote has a row of degree 1 065, epinions ~3 000, and a
+// single lane group walking such a row holds its whole workgroup for hundreds of microseconds
+// (measured on a Chung-Lu graph, 75k nodes / 1M edges, max degree 12 777: 2 244 us per Euler step
+// instead of 213).  So rows longer than HUB_T are taken out of the step kernels:
+//
+//   graph build  rows with degree > HUB_T become "hubs"; their neighbour lists are cut into
+//                segments of <= 32 edges (uniform work items).
+//   k_hub_seg    one lane group per (sample, segment): partial[b][s][:] = sum of the segment's
+//                neighbour rows, ascending column order inside the segment.
+//   k_hub_reduce one lane group per (sample, hub): AIhub[b][h][:] = partials of the hub summed in
+//                segment order (contiguous, coalesced reads).
+//   consumers    step / derivative / backward kernels read AIhub for hub rows and gather the rest.
+//
+// Deterministic (no atomics): a hub's sum is blocked by segment but always in the same order.
+// Up to two tables are reduced through the same index lists in one pass (the backward needs
+// A Z_I and A q).  Scratch lives in the graph handle and only ever grows, so after the first call
+// with a given batch size the launch path allocates nothing (hipGraph-capturable).
+#include "gnode_common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#define HUB_SEG 32
+
+static int hub_threshold() {
+    static const int v = [] { const char* e = getenv("GNODE_HUB_T"); int t = e ? atoi(e) : 48; return t < 4 ? 4 : t; }();
+    return v;
+}
+
+__device__ __forceinline__ float4 hld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void hst4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// partial[t][b][s][H]: one lane group (LPR lanes, 4 features each) per (sample b, segment s)
+template <int LPR>
+__global__ __launch_bounds__(256) void k_hub_seg(const int* __restrict__ seg_lo, const int* __restrict__ seg_hi,
+                                                 const int* __restrict__ col, int n, int n_seg, int H,
+                                                 const float* __restrict__ T0, const float* __restrict__ T1,
+                                                 float* __restrict__ P0, float* __restrict__ P1) {
+    const int sub = threadIdx.x % LPR;
+    const int s = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (s >= n_seg) return;
+    const bool active = 4 * sub < H;
+    const long b = blockIdx.y;
+    const float* t0 = T0 + (size_t)b * n * H;
+    const float* t1 = T1 ? T1 + (size_t)b * n * H : nullptr;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    const int lo = seg_lo[s], hi = seg_hi[s];
+    for (int e0 = lo; e0 < hi; e0 += LPR) {
+        const int cnt = min(LPR, hi - e0);
+        const int mine = (sub < cnt) ? col[e0 + sub] : 0;
+        for (int j = 0; j < cnt; j += 4) {
+            const int c0 = __shfl(mine, j, LPR), c1 = __shfl(mine, min(j + 1, LPR - 1), LPR);
+            const int c2 = __shfl(mine, min(j + 2, LPR - 1), LPR), c3 = __shfl(mine, min(j + 3, LPR - 1), LPR);
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 u0 = z, u1 = z, u2 = z, u3 = z, v0 = z, v1 = z, v2 = z, v3 = z;
+            if (active) {
+                u0 = hld4(t0 + (size_t)c0 * H + 4 * sub);
+                if (j + 1 < cnt) u1 = hld4(t0 + (size_t)c1 * H + 4 * sub);
+                if (j + 2 < cnt) u2 = hld4(t0 + (size_t)c2 * H + 4 * sub);
+                if (j + 3 < cnt) u3 = hld4(t0 + (size_t)c3 * H + 4 * sub);
+                if (t1) {
+                    v0 = hld4(t1 + (size_t)c0 * H + 4 * sub);
+                    if (j + 1 < cnt) v1 = hld4(t1 + (size_t)c1 * H + 4 * sub);
+                    if (j + 2 < cnt) v2 = hld4(t1 + (size_t)c2 * H + 4 * sub);
+                    if (j + 3 < cnt) v3 = hld4(t1 + (size_t)c3 * H + 4 * sub);
+                }
+            }
+#define HUB_ACC(A, V) A.x += V.x; A.y += V.y; A.z += V.z; A.w += V.w;
+            HUB_ACC(a0, u0) HUB_ACC(a0, u1) HUB_ACC(a0, u2) HUB_ACC(a0, u3)
+            HUB_ACC(a1, v0) HUB_ACC(a1, v1) HUB_ACC(a1, v2) HUB_ACC(a1, v3)
+        }
+    }
+    if (!active) return;
+    const size_t o = ((size_t)b * n_seg + s) * H + 4 * sub;
+    hst4(P0 + o, a0);
+    if (t1) hst4(P1 + o, a1);
+}
+
+// AIhub[t][b][h][H] = sum over the hub's segments, in segment order
+template <int LPR>
+__global__ __launch_bounds__(256) void k_hub_reduce(const int* __restrict__ hub_seg_ptr, int n_hub, int n_seg, int H,
+                                                    const float* __restrict__ P0, const float* __restrict__ P1,
+                                                    float* __restrict__ A0, float* __restrict__ A1) {
+    const int sub = threadIdx.x % LPR;
+    const int h = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (h >= n_hub || 4 * sub >= H) return;
+    const long b = blockIdx.y;
+    const int s0 = hub_seg_ptr[h], s1 = hub_seg_ptr[h + 1];
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    const float* p0 = P0 + ((size_t)b * n_seg) * H + 4 * sub;
+    const float* p1 = P1 ? P1 + ((size_t)b * n_seg) * H + 4 * sub : nullptr;
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+        const float4 u0 = hld4(p0 + (size_t)s * H), u1 = hld4(p0 + (size_t)(s + 1) * H);
+        const float4 u2 = hld4(p0 + (size_t)(s + 2) * H), u3 = hld4(p0 + (size_t)(s + 3) * H);
+        HUB_ACC(a0, u0) HUB_ACC(a0, u1) HUB_ACC(a0, u2) HUB_ACC(a0, u3)
+        if (p1) {
+            const float4 v0 = hld4(p1 + (size_t)s * H), v1 = hld4(p1 + (size_t)(s + 1) * H);
+            const float4 v2 = hld4(p1 + (size_t)(s + 2) * H), v3 = hld4(p1 + (size_t)(s + 3) * H);
+            HUB_ACC(a1, v0) HUB_ACC(a1, v1) HUB_ACC(a1, v2) HUB_ACC(a1, v3)
+        }
+    }
+    for (; s < s1; ++s) {
+        const float4 u = hld4(p0 + (size_t)s * H);
+        HUB_ACC(a0, u)
+        if (p1) { const float4 v = hld4(p1 + (size_t)s * H); HUB_ACC(a1, v) }
+    }
+#undef HUB_ACC
+    const size_t o = ((size_t)b * n_hub + h) * H + 4 * sub;
+    hst4(A0 + o, a0);
+    if (p1) hst4(A1 + o, a1);
+}
+
+// --------------------------------------------------------------------------- host: build + launch
+int gn_hub_build(gnode_graph_s* g, const int32_t* rowptr_host) {
+    const int T = hub_threshold();
+    std::vector<int32_t> hubidx((size_t)g->n, -1), seg_lo, seg_hi, hub_seg_ptr(1, 0);
+    int n_hub = 0;
+    for (int32_t r = 0; r < g->n; ++r) {
+        const int32_t lo = rowptr_host[r], hi = rowptr_host[r + 1];
+        if (hi - lo <= T) continue;
+        hubidx[r] = n_hub++;
+        for (int32_t e = lo; e < hi; e += HUB_SEG) {
+            seg_lo.push_back(e);
+            seg_hi.push_back(std::min(hi, e + HUB_SEG));
+        }
+        hub_seg_ptr.push_back((int32_t)seg_lo.size());
+    }
+    g->n_hub = n_hub;
+    g->n_seg = (int32_t)seg_lo.size();
+    g->hubidx = g->seg_lo = g->seg_hi = g->hub_seg_ptr = nullptr;
+    g->hub_scratch = nullptr;
+    g->hub_scratch_bytes = 0;
+    if (n_hub == 0) return 0;
+    auto up = [](int32_t** dst, const std::vector<int32_t>& v) -> hipError_t {
+        hipError_t e = hipMalloc(dst, sizeof(int32_t) * v.size());
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice);
+    };
+    GN_HIP(up(&g->hubidx, hubidx));
+    GN_HIP(up(&g->seg_lo, seg_lo));
+    GN_HIP(up(&g->seg_hi, seg_hi));
+    GN_HIP(up(&g->hub_seg_ptr, hub_seg_ptr));
+    return 0;
+}
+
+void gn_hub_free(gnode_graph_s* g) {
+    if (g->hubidx) (void)hipFree(g->hubidx);
+    if (g->seg_lo) (void)hipFree(g->seg_lo);
+    if (g->seg_hi) (void)hipFree(g->seg_hi);
+    if (g->hub_seg_ptr) (void)hipFree(g->hub_seg_ptr);
+    if (g->hub_scratch) (void)hipFree(g->hub_scratch);
+}
+
+static int hub_lpr(int H) {
+    int need = H / 4, l = 1;
+    while (l < need) l <<= 1;
+    return l;
+}
+
+#define HUB_DISPATCH(lpr, ...)                                   \
+    switch (lpr) {                                               \
+        case 1: { constexpr int LPR = 1; __VA_ARGS__; } break;   \
+        case 2: { constexpr int LPR = 2; __VA_ARGS__; } break;   \
+        case 4: { constexpr int LPR = 4; __VA_ARGS__; } break;   \
+        case 8: { constexpr int LPR = 8; __VA_ARGS__; } break;   \
+        case 16: { constexpr int LPR = 16; __VA_ARGS__; } break; \
+        case 32: { constexpr int LPR = 32; __VA_ARGS__; } break; \
+        default: { constexpr int LPR = 64; __VA_ARGS__; } break; \
+    }
+
+// Hub sums of one or two tables [B*n][H] (T1 may be null).  On return *A0 / *A1 point at [B][n_hub][H]
+// buffers inside the handle's scratch, valid until the next call on this handle.
+int gn_hub_gather(gnode_graph_s* g, long B, int H, const float* T0, const float* T1, const float** A0, const float** A1,
+                  hipStream_t st) {
+    *A0 = nullptr;
+    if (A1) *A1 = nullptr;
+    if (g->n_hub == 0) return 0;
+    const int nt = T1 ? 2 : 1;
+    const size_t part_f = (size_t)B * g->n_seg * H, hub_f = (size_t)B * g->n_hub * H;
+    const size_t need = gn_align(sizeof(float) * part_f) * 2 + gn_align(sizeof(float) * hub_f) * 2;
+    if (g->hub_scratch_bytes < need) {          // grow-only cache: no allocation once warmed up for this batch size
+        GN_HIP(hipStreamSynchronize(st));
+        if (g->hub_scratch) GN_HIP(hipFree(g->hub_scratch));
+        g->hub_scratch = nullptr; g->hub_scratch_bytes = 0;
+        GN_HIP(hipMalloc(&g->hub_scratch, need));
+        g->hub_scratch_bytes = need;
+    }
+    char* base = (char*)g->hub_scratch;
+    float* P0 = (float*)base;
+    float* P1 = (float*)(base + gn_align(sizeof(float) * part_f));
+    float* a0 = (float*)(base + 2 * gn_align(sizeof(float) * part_f));
+    float* a1 = (float*)(base + 2 * gn_align(sizeof(float) * part_f) + gn_align(sizeof(float) * hub_f));
+    const int lpr = hub_lpr(H), gpw = 256 / lpr;
+    HUB_DISPATCH(lpr, hipLaunchKernelGGL(k_hub_seg<LPR>, dim3((unsigned)((g->n_seg + gpw - 1) / gpw), (unsigned)B), dim3(256), 0, st,
+                                         g->seg_lo, g->seg_hi, g->col, g->n, g->n_seg, H, T0, T1, P0, P1));
+    GN_LAUNCH_CHECK();
+    HUB_DISPATCH(lpr, hipLaunchKernelGGL(k_hub_reduce<LPR>, dim3((unsigned)((g->n_hub + gpw - 1) / gpw), (unsigned)B), dim3(256), 0,
+                                         st, g->hub_seg_ptr, g->n_hub, g->n_seg, H, P0, nt == 2 ? P1 : nullptr, a0, a1));
+    GN_LAUNCH_CHECK();
+    *A0 = a0;
+    if (A1) *A1 = nt == 2 ? a1 : nullptr;
+    return 0;
+}

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void k_gather(const int* __restrict__ rowptr, 
                                                 const float* __restrict__ beta, const float* __restrict__ gamma,
                                                 int bg_stride, float dt, float* __restrict__ dY,
                                                 const float* __restrict__ w3, const float* __restrict__ b3,
-                                                const float* __restrict__ w2, const float* __restrict__ b2, StepOut out) {
+                                                const float* __restrict__ w2, const float* __restrict__ b2, StepOut out,
+                                                const int* __restrict__ hubidx, const float* __restrict__ AIhub, int n_hub) {
     const int sub = threadIdx.x % LPR;
     const int node = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (node >= n) return;                       // whole lane group leaves together
@@ -245,7 +246,10 @@ __global__ __launch_bounds__(256) void k_gather(const int* __restrict__ rowptr, 
     const float* ZS = Z;
     const float* ZI = Z + slab;
 
-    const float4 ai = gather_row<LPR>(rowptr, col, ZI + (size_t)base * H, node, sub, active, H);
+    const int hub = hubidx ? hubidx[node] : -1;  // long rows were summed by the hub kernels (gnode_hub.hip)
+    float4 ai;
+    if (hub >= 0) ai = active ? ld4(AIhub + ((size_t)blockIdx.y * n_hub + hub) * H + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+    else ai = gather_row<LPR>(rowptr, col, ZI + (size_t)base * H, node, sub, active, H);
     float4 zs = make_float4(0.f, 0.f, 0.f, 0.f), zi = zs;
     if (active) { zs = ld4(ZS + off); zi = ld4(ZI + off); }
     const float nb = -beta[(size_t)r * bg_stride], gm = gamma[(size_t)r * bg_stride];
@@ -380,13 +384,15 @@ static int launch_gather(gnode_graph_t g, int mode, long rows, int H, float* Y, 
     dim3 grid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)B);
     const float *w3 = p ? p->linear3_weight : nullptr, *b3 = p ? p->linear3_bias : nullptr;
     const float *w2 = p ? p->linearS2_weight : nullptr, *b2 = p ? p->linearS2_bias : nullptr;
+    const float* AIhub = nullptr;
+    if (int e = gn_hub_gather(g, B, H, Z + (size_t)rows * H, nullptr, &AIhub, nullptr, st)) return e;
     const bool sampled = mode == 1 && prof_begin(0, st);
     if (mode == 0) {
         DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_gather<LPR, 0>), grid, dim3(256), 0, st, g->rowptr, g->col, g->n, rows, H,
-                                             Y, Z, beta, gamma, bg_stride, dt, dY, w3, b3, w2, b2, out));
+                                             Y, Z, beta, gamma, bg_stride, dt, dY, w3, b3, w2, b2, out, g->hubidx, AIhub, g->n_hub));
     } else {
         DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_gather<LPR, 1>), grid, dim3(256), 0, st, g->rowptr, g->col, g->n, rows, H,
-                                             Y, Z, beta, gamma, bg_stride, dt, dY, w3, b3, w2, b2, out));
+                                             Y, Z, beta, gamma, bg_stride, dt, dY, w3, b3, w2, b2, out, g->hubidx, AIhub, g->n_hub));
     }
     if (sampled) prof_mark(0, st);
     GN_LAUNCH_CHECK();
@@ -420,6 +426,8 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
                      (long long)e, col_host[e]);
     gnode_graph_s* g = new gnode_graph_s();
     g->n = n; g->nnz = nnz; g->max_degree = maxdeg; g->rowptr = nullptr; g->col = nullptr;
+    g->n_hub = g->n_seg = 0; g->hubidx = g->seg_lo = g->seg_hi = g->hub_seg_ptr = nullptr;
+    g->hub_scratch = nullptr; g->hub_scratch_bytes = 0;
     hipError_t e1 = hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n + 1));
     hipError_t e2 = hipMalloc(&g->col, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -438,12 +446,20 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
         delete g;
         return GNODE_ERR_HIP;
     }
+    if (int e = gn_hub_build(g, rowptr_host)) {
+        gn_hub_free(g);
+        (void)hipFree(g->rowptr);
+        (void)hipFree(g->col);
+        delete g;
+        return e;
+    }
     *out = g;
     return 0;
 }
 
 extern "C" int gnode_graph_destroy(gnode_graph_t g) {
     if (!g) return 0;
+    gn_hub_free(g);
     (void)hipFree(g->rowptr);
     (void)hipFree(g->col);
     delete g;

@@ -565,3 +565,25 @@ def adjoint_grads_torch(x, P, rowptr, col, maxTime, deltaT, gS, gI, gR, out_rows
     ge = torch.autograd.grad(y0, [Pt["linearS1.weight"], Pt["linearS1.bias"]], a)
     grads["linearS1.weight"], grads["linearS1.bias"] = ge
     return {k: v.detach().numpy() for k, v in grads.items()}
+
+
+def chung_lu_graph(n, m, exponent=0.8, seed=0):
+    """Skewed-degree test graph (Chung-Lu: endpoints drawn with probability ~ (rank+1)^-exponent):
+    m distinct undirected edges, no self-loops; hubs of degree ~ n/10 like wiki-vote / epinions.
+    Returns (rowptr, col, undirected_edges)."""
+    rng = np.random.default_rng(seed)
+    w = (np.arange(n) + 1.0) ** (-exponent)
+    p = w / w.sum()
+    have = np.empty(0, dtype=np.int64)
+    while have.shape[0] < m:
+        k = int((m - have.shape[0]) * 1.5) + 64
+        u = rng.choice(n, size=k, p=p)
+        v = rng.choice(n, size=k, p=p)
+        ok = u != v
+        lo, hi = np.minimum(u, v)[ok], np.maximum(u, v)[ok]
+        have = np.unique(np.concatenate([have, lo.astype(np.int64) * n + hi]))
+        if have.shape[0] > m:
+            have = np.sort(rng.permutation(have)[:m])
+    e = np.stack([have // n, have % n], 1)
+    rp, ci = csr_from_edges(n, e)
+    return rp, ci, e

@@ -26,12 +26,12 @@ def _rel(a, b):
     (90, 300, 2, 32, 4, 0.25, False),
     (40, 100, 1, 128, 3, 0.5, False),
 ])
-def test_param_grads_vs_oracle(n, m, B, H, maxTime, deltaT, sub, dev):
+def test_param_grads_vs_oracle(n, m, B, H, maxTime, deltaT, sub, dev, skewed=False):
     import torch
     import gnode_oracle as O
     from gnode import ops
     from gnode.graph import DeviceGraph
-    rp, ci, _ = O.er_graph(n, m, seed=n + H)
+    rp, ci, _ = (O.chung_lu_graph if skewed else O.er_graph)(n, m, seed=n + H)
     P = O.init_params(H, seed=H + 1)
     x = O.make_samples(n, B, H, seed=B)
     grid = O.time_grid(maxTime, deltaT)
@@ -55,6 +55,12 @@ def test_param_grads_vs_oracle(n, m, B, H, maxTime, deltaT, sub, dev):
         assert err <= 2e-4, f"{k}: rel err {err:.2e}"
     # linearS2.bias: softmax is shift invariant -> exact gradient 0; ours must be ~0 relative to the others
     assert abs(float(got["linearS2.bias"].cpu())) <= 1e-4 * max(1.0, float(np.abs(want["linearS2.weight"]).max()))
+
+
+@pytest.mark.parametrize("H", [64, 16])
+def test_param_grads_on_skewed_graph(H, dev):
+    """Hub rows (degree >> hub threshold) in the backward's two transposed gathers."""
+    test_param_grads_vs_oracle(600, 6000, 2, H, 4, 0.5, False, dev, skewed=True)
 
 
 def test_autograd_training_step_reduces_loss(dev):
