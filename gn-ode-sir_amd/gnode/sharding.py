@@ -23,6 +23,28 @@ def shard_range(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def init_from_env():
+    """One process per GPU under torchrun: bind this rank to cuda:LOCAL_RANK and join the RCCL
+    (backend "nccl") process group.  No-op for a plain single-process run.  Returns (rank, world)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
+            backend = os.environ.get("GNODE_DIST_BACKEND", "nccl")
+        else:
+            backend = "gloo"
+        dist.init_process_group(backend)
+    return world_info()
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
 def world_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()

@@ -119,7 +119,10 @@ class Runner:
         self.rank, self.world = sharding.world_info()
         seed = torch.randint(0, 2**31 - 1, (1,))
         if self.world > 1:
+            seed = seed.to(device)
             torch.distributed.broadcast(seed, src=0)
+            for p in model.parameters():                 # every rank starts from rank 0's initialisation
+                torch.distributed.broadcast(p.data, src=0)
         self.seed = int(seed.item())
 
     def batches(self, n_items, batch_size, shuffle, epoch=0):
@@ -251,15 +254,21 @@ def main_single(argv=None):
     args = parser_single().parse_args(argv)
     if args.model != "ode_nn":
         raise SystemExit(f"this entry point serves model='ode_nn' only (got {args.model!r})")
+    rank, world = sharding.init_from_env()        # torchrun: one process per GPU; plain run: (0, 1)
     G, A, _ = create_graph(50, args.dataset)
     n_nodes = A.shape[0]
     print(n_nodes)
     args.I_indices = [list(map(int, str(i)[1:-1].split(", "))) for i in args.I_indices]      # "[25, 18]" -> [25, 18]
-    if not os.path.exists(args.path_to_save + "/initial-seed.pkl"):
+    if rank == 0 and not os.path.exists(args.path_to_save + "/initial-seed.pkl"):
         pickle.dump(args.I_indices, open(args.path_to_save + "/initial-seed.pkl", "wb"))
         pickle.dump(args.beta, open(args.path_to_save + "/initial-beta.pkl", "wb"))
         pickle.dump(args.gamma, open(args.path_to_save + "/initial-gamma.pkl", "wb"))
     xs, ys = [], []
+    if world > 1:                                  # rank 0 fills the label cache, the others read it
+        if rank == 0:
+            for i, seeds in enumerate(args.I_indices):
+                load_SIR_labels(args.dataset, args.path_to_save, G, seeds, args.beta[i], args.gamma[i], args.sim, args.maxTime)
+        sharding.barrier()
     for i, seeds in enumerate(args.I_indices):
         S, I, R = load_SIR_labels(args.dataset, args.path_to_save, G, seeds, args.beta[i], args.gamma[i], args.sim, args.maxTime)
         y = torch.from_numpy(np.stack([np.asarray(S), np.asarray(I), np.asarray(R)], -1)).transpose(0, 1)   # [n, T, 3] float64
@@ -267,7 +276,7 @@ def main_single(argv=None):
         ys.append(y.contiguous())
     ood = pickle.load(open(args.path_to_save + "/out-of-dist-gamma.pkl", "rb")) if args.out_of_dist else None
     tr, va, te = split_indices(len(xs), args.train_val_test_ratio, ood)
-    device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     torch.set_default_dtype(torch.float32)
     print(device)
     odefunc = ODEfunc(A, args.beta[0], args.gamma[0], args.hidden, device)
@@ -286,6 +295,8 @@ def main_single(argv=None):
             t0 = time.time()
             test_loss, test_all = run.evaluate(*pick(te), 1)
             t_test = time.time() - t0
+    if rank != 0:
+        return 0
     if not args.out_of_dist:
         save_trial_to_csv(args, best_epoch, best_loss, test_loss, 0, t_test, 0)
     else:
@@ -334,6 +345,7 @@ def main_multi(argv=None):
     args = parser_multi().parse_args(argv)
     if args.model != "ode_nn":
         raise SystemExit(f"this entry point serves model='ode_nn' only (got {args.model!r})")
+    rank, world = sharding.init_from_env()
     names = args.dataset[14:].split("+")
     A_list = []
     for gname in names:                                             # create_graphs, ode_nn_ngraphs.py:154-165
@@ -372,7 +384,7 @@ def main_multi(argv=None):
                 dst = te
             dst[0].append(x)
             dst[1].append(y)
-    device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     torch.set_default_dtype(torch.float32)
     print(device)
     odefunc = ODEfunc(A_list, args.hidden, device)
@@ -390,6 +402,8 @@ def main_multi(argv=None):
             t0 = time.time()
             test_loss, _ = run.evaluate(te[0], te[1], args.batch_size)
             t_test = time.time() - t0
+    if rank != 0:
+        return 0
     csv_trials(args.path_to_save + "/Metrics-trials-" + os.path.relpath(args.dataset, "./real_graphs/"),
                ["trial", "model", "lr", "epochs", "deltaT", "maxTime", "hidden", "best_epoch", "val_loss", "test_loss", "n_ode_time"],
                [args.trial, args.model, args.lr, args.epochs, args.deltaT, args.maxTime, args.hidden, best_epoch, best_loss,

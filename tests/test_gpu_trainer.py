@@ -121,3 +121,29 @@ def test_graph_replay_equals_eager(dev):
         hist.append((losses, [p.detach().clone() for p in model.parameters()]))
     assert hist[0][0] == hist[1][0]
     assert all(torch.equal(a, b) for a, b in zip(hist[0][1], hist[1][1]))
+
+
+def test_two_rank_entry_point(tmp_path, dev):
+    """torchrun, 2 ranks (both on the one GPU of the box, gloo control plane because RCCL refuses two ranks on
+    one device): samples of every batch are sharded, gradients all-reduced, rank 0 alone writes the files."""
+    import subprocess
+    import sys
+    import pandas as pd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(tmp_path / "real_graphs"); os.makedirs(tmp_path / "multi-graph-1" / "Experiments-seed2-toy")
+    G = _mk_graph(str(tmp_path / "real_graphs" / "toy.pkl"), 60, 180, 4)
+    n = G.number_of_nodes()
+    rng = np.random.default_rng(1)
+    seeds = [sorted(rng.choice(n, 2, replace=False).tolist()) for _ in range(8)]
+    argv = ["--lr", "0.01", "--epochs", "2", "--hidden", "64", "--I_indices"] + [str(s) for s in seeds] + \
+           ["--beta"] + ["0.3"] * 8 + ["--gamma"] + ["0.2"] * 8 + \
+           ["--deltaT", "0.5", "--maxTime", "6", "--sim", "100", "--trial", "0", "--dataset", "./real_graphs/toy",
+            "--path_to_save", "./multi-graph-1/Experiments-seed2-toy", "--batch_size", "4",
+            "--train_val_test_ratio", "0.5", "0.25", "0.25", "--model", "ode_nn"]
+    env = dict(os.environ, GNODE_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "gn-ode-sir_amd", "scripts", "ode_nn_ngraph_sim.py")] + argv
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    df = pd.read_csv(tmp_path / "multi-graph-1" / "Experiments-seed2-toy" / "Metrics-trials-toy")
+    assert len(df) == 1 and np.isfinite(df["val_loss"][0]) and np.isfinite(df["test_loss"][0])
