@@ -56,14 +56,39 @@ def label_paths(dataset, path_to_save, I_indices):
 def load_SIR_labels(dataset, path_to_save, G, I_indices, beta, gamma, sim, maxTime):
     """Label cache keyed by the seed set only (reference quirk Q4): load the three
     [T, n] probability arrays if present, else generate them with the Monte-Carlo kernel,
-    divide the counts by `sim` (ode_nn_ngraph_sim.py:199) and write the same files."""
+    divide the counts by `sim` (ode_nn_ngraph_sim.py:199) and write the same files.
+
+    Under torch.distributed this is a COLLECTIVE: the `sim` trajectories are split over the ranks
+    (coins are keyed by the global trajectory index), the uint32 [3,T,n] counts are all-reduced
+    once per sample, and rank 0 writes the cache."""
+    rank, world = sharding.world_info()
     ps = label_paths(dataset, path_to_save, I_indices)
-    if os.path.exists(ps[0]):
+    have = os.path.exists(ps[0])
+    if world > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        flag = torch.tensor([1 if have else 0], device=dev)
+        torch.distributed.broadcast(flag, src=0)
+        have = bool(flag.item())
+    if have:
         return tuple(pickle.load(open(p, "rb")) for p in ps)
-    S, I, R = sir_torch(G, I_indices, beta, gamma, sim, maxTime)
-    out = (S[0] / sim, I[0] / sim, R[0] / sim)
-    for p, a in zip(ps, out):
-        pickle.dump(a, open(p, "wb"))
+    if world == 1:
+        S, I, R = sir_torch(G, I_indices, beta, gamma, sim, maxTime)
+        out = (S[0] / sim, I[0] / sim, R[0] / sim)
+    else:
+        from .graph import DeviceGraph
+        from .ode_nn import _csr_from_edges, _edge_arrays, sir_counts
+        seed = torch.randint(0, 2**62, (1,), dtype=torch.int64).to(dev)
+        torch.distributed.broadcast(seed, src=0)
+        graph = DeviceGraph(*_csr_from_edges(G.number_of_nodes(), _edge_arrays(G)))
+        lo, hi = sharding.shard_range(sim, rank, world)
+        counts = sir_counts(graph, I_indices, beta, gamma, hi - lo, maxTime, int(seed.item()), sim_offset=lo)
+        sharding.allreduce_counts(counts)
+        c = (counts.cpu().numpy().astype(np.int64) & 0xFFFFFFFF).astype(np.float64)
+        out = (c[0] / sim, c[1] / sim, c[2] / sim)
+    if rank == 0:
+        for p, a in zip(ps, out):
+            pickle.dump(a, open(p, "wb"))
+    sharding.barrier()
     return out
 
 
@@ -264,11 +289,6 @@ def main_single(argv=None):
         pickle.dump(args.beta, open(args.path_to_save + "/initial-beta.pkl", "wb"))
         pickle.dump(args.gamma, open(args.path_to_save + "/initial-gamma.pkl", "wb"))
     xs, ys = [], []
-    if world > 1:                                  # rank 0 fills the label cache, the others read it
-        if rank == 0:
-            for i, seeds in enumerate(args.I_indices):
-                load_SIR_labels(args.dataset, args.path_to_save, G, seeds, args.beta[i], args.gamma[i], args.sim, args.maxTime)
-        sharding.barrier()
     for i, seeds in enumerate(args.I_indices):
         S, I, R = load_SIR_labels(args.dataset, args.path_to_save, G, seeds, args.beta[i], args.gamma[i], args.sim, args.maxTime)
         y = torch.from_numpy(np.stack([np.asarray(S), np.asarray(I), np.asarray(R)], -1)).transpose(0, 1)   # [n, T, 3] float64
