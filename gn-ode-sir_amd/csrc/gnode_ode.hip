@@ -277,6 +277,79 @@ __global__ __launch_bounds__(256) void k_gather(const int* __restrict__ rowptr, 
     }
 }
 
+// Fused Euler step for generic H (the multi-graph launcher trains with H = 8): the same launch
+// structure as k_step64 -- gather, Z_S from Y_S, update, read-out, next step's Z_I -- with the node
+// MLP as a lane-group mat-vec: the row's H values live 4 per lane, x_k is broadcast inside the group
+// by shuffle and multiplied with W^T (staged in LDS, [k][j]).
+template <int LPR>
+__device__ __forceinline__ float4 group_mlp(float4 x, const float* __restrict__ Wt, float4 bias4, int sub, bool active,
+                                            int H) {
+    float4 acc = bias4;
+    const float xv[4] = {x.x, x.y, x.z, x.w};
+    for (int kk = 0; 4 * kk < H; ++kk) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float xk = __shfl(xv[c], kk, LPR);
+            if (active) {
+                const float4 w = ld4(Wt + (size_t)(4 * kk + c) * H + 4 * sub);
+                acc.x = fmaf(xk, w.x, acc.x); acc.y = fmaf(xk, w.y, acc.y);
+                acc.z = fmaf(xk, w.z, acc.z); acc.w = fmaf(xk, w.w, acc.w);
+            }
+        }
+    }
+    return make_float4(gn_sigmoid(acc.x), gn_sigmoid(acc.y), gn_sigmoid(acc.z), gn_sigmoid(acc.w));
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_step_generic(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+                                                      long rows, int H, float* __restrict__ Y,
+                                                      const float* __restrict__ ZI, float* __restrict__ ZI_next,
+                                                      const float* __restrict__ W, const float* __restrict__ bias,
+                                                      const float* __restrict__ beta, const float* __restrict__ gamma,
+                                                      float dt, const float* __restrict__ w3, const float* __restrict__ b3,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      StepOut out, const int* __restrict__ hubidx,
+                                                      const float* __restrict__ AIhub, int n_hub) {
+    extern __shared__ float Wt[];                 // [H][H] transposed: Wt[k][j] = W[j][k]
+    for (int idx = threadIdx.x; idx < H * H; idx += 256) Wt[(size_t)(idx % H) * H + idx / H] = W[idx];
+    __syncthreads();
+    const int sub = threadIdx.x % LPR;
+    const int node = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (node >= n) return;                        // whole lane group leaves together (no barrier after this point)
+    const bool active = 4 * sub < H;
+    const long base = (long)blockIdx.y * n, r = base + node;
+    const size_t slab = (size_t)rows * H, off = (size_t)r * H + 4 * sub;
+    const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bias4 = active ? ld4(bias + 4 * sub) : z0;
+
+    const int hub = hubidx ? hubidx[node] : -1;
+    float4 ai;
+    if (hub >= 0) ai = active ? ld4(AIhub + ((size_t)blockIdx.y * n_hub + hub) * H + 4 * sub) : z0;
+    else ai = gather_row<LPR>(rowptr, col, ZI + (size_t)base * H, node, sub, active, H);
+    float4 yS = z0, yI = z0, yR = z0, zi = z0;
+    if (active) { yS = ld4(Y + off); yI = ld4(Y + slab + off); yR = ld4(Y + 2 * slab + off); zi = ld4(ZI + off); }
+    const float4 zs = group_mlp<LPR>(yS, Wt, bias4, sub, active, H);
+    const float nb = -beta[r], gm = gamma[r];
+    float4 dS, dI, dR;
+    dS.x = nb * (ai.x * zs.x); dS.y = nb * (ai.y * zs.y); dS.z = nb * (ai.z * zs.z); dS.w = nb * (ai.w * zs.w);
+    dR.x = gm * zi.x; dR.y = gm * zi.y; dR.z = gm * zi.z; dR.w = gm * zi.w;
+    dI.x = -dS.x - dR.x; dI.y = -dS.y - dR.y; dI.z = -dS.z - dR.z; dI.w = -dS.w - dR.w;
+    yS.x += dt * dS.x; yS.y += dt * dS.y; yS.z += dt * dS.z; yS.w += dt * dS.w;
+    yI.x += dt * dI.x; yI.y += dt * dI.y; yI.z += dt * dI.z; yI.w += dt * dI.w;
+    yR.x += dt * dR.x; yR.y += dt * dR.y; yR.z += dt * dR.z; yR.w += dt * dR.w;
+    if (active) {
+        st4(Y + off, yS); st4(Y + slab + off, yI); st4(Y + 2 * slab + off, yR);
+        if (out.sol) { st4(out.sol + off, yS); st4(out.sol + slab + off, yI); st4(out.sol + 2 * slab + off, yR); }
+    }
+    if (out.S) {
+        float pS, pI, pR;
+        readout_row<LPR>(yS, yI, yR, active, sub, H, w3, b3, w2, b2, pS, pI, pR);
+        if (sub == 0) { out.S[r] = pS; out.I[r] = pI; out.R[r] = pR; }
+    }
+    const float4 zn = group_mlp<LPR>(yI, Wt, bias4, sub, active, H);     // Z_I of the next step
+    if (active) st4(ZI_next + off, zn);
+}
+
 // Stand-alone read-out of a state (grid point 0, and every point under RK4).
 template <int LPR>
 __global__ __launch_bounds__(256) void k_readout(const float* __restrict__ Y, long rows, int H,
@@ -571,7 +644,7 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
     // inference (no trajectory requested): R only feeds the read-out -> carry its 4-float projection
     static const bool prj_ok = [] { const char* e = getenv("GNODE_PRJ"); return !(e && e[0] == '0'); }();
     float* PR = (h64 && !sol && prj_ok) ? prbuf : nullptr;
-    if (h64 && n_steps > 0) {
+    if ((h64 || (method == 0 && H <= 128)) && n_steps > 0) {
         if (int e = launch_mlp(Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
         if (PR) if (int e = gn_launch_init_pr64(Y + 2 * slab, p->linear3_weight, PR, rows, st)) return e;
     }
@@ -591,6 +664,28 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
             if (fuse_zi) std::swap(zi_cur, zi_nxt);
             else if (k + 1 < n_steps)
                 if (int e = launch_mlp(Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
+        } else if (method == 0 && H <= 128) {
+            // generic H: one fused launch per step (gather + both node MLPs as lane-group mat-vecs)
+            StepOut out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
+                           slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
+            const float* AIhub = nullptr;
+            if (int e = gn_hub_gather(g, rows / g->n, H, zi_cur, nullptr, &AIhub, nullptr, st)) return e;
+            dim3 grid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)(rows / g->n));
+            const size_t lds = (size_t)H * H * sizeof(float);
+            const bool sampled = prof_begin(0, st);
+            DISPATCH_LPR(lpr, {
+                static bool attr_set = false;
+                if (lds > 64 * 1024 && !attr_set) {
+                    GN_HIP(hipFuncSetAttribute((const void*)k_step_generic<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL(k_step_generic<LPR>, grid, dim3(256), lds, st, g->rowptr, g->col, g->n, (long)rows, H, Y, zi_cur,
+                                   zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma, dt, p->linear3_weight,
+                                   p->linear3_bias, p->linearS2_weight, p->linearS2_bias, out, g->hubidx, AIhub, g->n_hub);
+            });
+            if (sampled) prof_mark(0, st);
+            GN_LAUNCH_CHECK();
+            std::swap(zi_cur, zi_nxt);
         } else if (method == 0) {
             if (int e = launch_mlp(Y, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
             StepOut out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
