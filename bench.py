@@ -156,9 +156,9 @@ def main():
     traffic = None
     try:
         import glob
-        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_step64.json")))
-        if pm and (n, nnz, H, chunk) == (75000, 1000000, 64, 8):
-            traffic = float(json.load(open(pm[-1]))["traffic_bytes_per_launch"])
+        pm = os.path.join(ROOT, "profiles", "pmc_step64_latest.json")
+        if os.path.exists(pm) and (n, nnz, H, chunk) == (75000, 1000000, 64, 8):
+            traffic = float(json.load(open(pm))["traffic_bytes_per_launch"])
     except Exception:
         traffic = None
 

@@ -7,7 +7,7 @@ cd $R
 timeout -k 10 700 python -m pytest tests -m gpu -x -q -s > gpurun_out/test.log 2>&1; rc=$?
 echo "tests rc=$rc"; tail -n 25 gpurun_out/test.log
 if [ $rc -ge 124 ]; then exit $rc; fi
-timeout -k 10 500 python bench.py --steps ${BENCH_STEPS:-3} --warmup 1 $BENCH_ARGS > gpurun_out/bench.json 2> gpurun_out/bench.err; rc=$?
+timeout -k 10 500 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 $BENCH_ARGS > gpurun_out/bench.json 2> gpurun_out/bench.err; rc=$?
 echo "bench rc=$rc"; cat gpurun_out/bench.json; tail -n 5 gpurun_out/bench.err
 if [ $rc -ne 0 ]; then exit $rc; fi
 cd /tmp && export TMPDIR=/tmp
