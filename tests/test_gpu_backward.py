@@ -90,6 +90,6 @@ def test_autograd_training_step_reduces_loss(dev):
         loss = crit(pred, y.view(-1, y.size(2), y.size(3))[:, 1:, :])        # ode_nn_ngraph_sim.py:234
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(p.grad is not None for k, p in model.named_parameters() if not k.endswith(("ln.weight", "ln.bias")))
     assert losses[-1] < losses[0]

@@ -423,3 +423,30 @@ def test_skewed_degree_graph_vs_oracle(n, m, B, H, method, dev):
     p = _tp(P, dev)
     dx = ops.rhs(g, torch.from_numpy(st).to(dev), p["odefunc.linear.weight"], p["odefunc.linear.bias"]).cpu().numpy()
     assert _rel(dx, OC.rhs(rp, ci, n, st, P["odefunc.linear.weight"], P["odefunc.linear.bias"])) <= RTOL
+
+
+@pytest.mark.parametrize("n,edges,B,H", [(1, [], 2, 64), (3, [(0, 1), (1, 2)], 3, 64), (5, [(0, 4), (2, 2)], 2, 4),
+                                         (2, [(0, 1)], 1, 8), (33, [(i, i + 1) for i in range(32)], 2, 64)])
+def test_tiny_graphs_and_small_hidden(n, edges, B, H, dev):
+    """Degenerate shapes: a single isolated node (nnz = 0), graphs smaller than one 32-row tile, a self-loop,
+    H = 4 (one lane per row), a path graph that spills one row into a second tile."""
+    import torch
+    import gnode_oracle as O
+    from gnode import ops
+    from gnode.graph import DeviceGraph
+    if edges:
+        rp, ci = O.csr_from_edges(n, edges)
+    else:
+        rp, ci = np.zeros(n + 1, np.int32), np.zeros(0, np.int32)
+    P = O.init_params(H, seed=n)
+    x = O.make_samples(n, B, H, seed=1, n_seeds=1)
+    g = DeviceGraph(rp, ci)
+    S, I, R, sol = ops.forward(g, torch.from_numpy(x).to(dev).reshape(B * n, 3 + H), _tp(P, dev),
+                               ops.step_sizes(ops.time_grid(4, 0.5)), want_sol=True)
+    So, Io, Ro, sol_o = O.odeblock_forward_single(x, P, rp, ci, 4, 0.5, return_sol=True)
+    for got, w in zip((S, I, R), (So, Io, Ro)):
+        assert _rel(got.cpu().numpy(), w[..., 0]) <= RTOL
+    assert _rel(sol.cpu().numpy(), sol_o) <= RTOL
+    S2, _, _, _ = ops.forward(g, torch.from_numpy(x).to(dev).reshape(B * n, 3 + H), _tp(P, dev),
+                              ops.step_sizes(ops.time_grid(4, 0.5)))
+    assert _rel(S2.cpu().numpy(), So[..., 0]) <= RTOL
