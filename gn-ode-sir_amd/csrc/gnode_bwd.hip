@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_bwd_mlp(const float* __restrict__ dpre,
     const bool lane_ok = 4 * sub < H;
     const size_t slab = (size_t)rows * H;
     const int nE = H * H;
-    constexpr int MAXM = 64;                   // entries of gW per thread: H*H/256 <= 64 for H <= 128
+    constexpr int MAXM = (LPR * LPR / 16) < 1 ? 1 : (LPR * LPR / 16);   // gW entries per thread: H*H/256 with H <= 4*LPR
     float accW[MAXM];
 #pragma unroll
     for (int m = 0; m < MAXM; ++m) accW[m] = 0.f;

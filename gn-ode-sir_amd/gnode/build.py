@@ -35,14 +35,18 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
     hipcc = _hipcc()
-    objs = []
-    for src in SOURCES:
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(src):
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:   # one hipcc per translation unit
+        objs = list(pool.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
