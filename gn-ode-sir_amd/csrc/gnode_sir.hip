@@ -270,7 +270,8 @@ extern "C" int gnode_sir_mc_coins(const int32_t* table_src, const int32_t* table
                                   int64_t* coins_used_host, void* workspace, size_t workspace_bytes, void* stream) {
     GN_CHECK_ARG(table_src && table_dst && counts && workspace && coins_used_host && (coins || n_coins == 0),
                  "gnode_sir_mc_coins: null pointer");
-    GN_CHECK_ARG(n > 0 && (size_t)2 * n <= 64 * 1024, "gnode_sir_mc_coins: parity mode supports n <= 32768 (got %d)", n);
+    GN_CHECK_ARG(n > 0 && (size_t)2 * n <= kLdsStateLimit, "gnode_sir_mc_coins: parity mode supports n <= %zu (got %d)",
+                 kLdsStateLimit / 2, n);
     GN_CHECK_ARG(n_seeds >= 0 && n_seeds <= 4096 && T >= 1 && sims >= 0 && n_table >= 0, "gnode_sir_mc_coins: bad sizes");
     for (int i = 0; i < n_seeds; ++i)
         GN_CHECK_ARG(seeds_host[i] >= 0 && seeds_host[i] < n, "gnode_sir_mc_coins: seed %d out of range", seeds_host[i]);
@@ -282,6 +283,8 @@ extern "C" int gnode_sir_mc_coins(const int32_t* table_src, const int32_t* table
     int32_t* seeds = (int32_t*)workspace;
     long long* used = (long long*)((char*)workspace + gn_align(4096 * sizeof(int32_t)));
     if (n_seeds) GN_HIP(hipMemcpyAsync(seeds, seeds_host, sizeof(int32_t) * n_seeds, hipMemcpyHostToDevice, st));
+    if ((size_t)2 * n > 64 * 1024)
+        GN_HIP(hipFuncSetAttribute((const void*)k_sir_coins, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * n));
     hipLaunchKernelGGL(k_sir_coins, dim3(1), dim3(256), (size_t)2 * n, st, table_src, table_dst, (long)n_table, n, seeds,
                        n_seeds, beta, gamma, (long)sims, T, coins, (long)n_coins, counts, used);
     GN_LAUNCH_CHECK();

@@ -450,3 +450,25 @@ def test_tiny_graphs_and_small_hidden(n, edges, B, H, dev):
     S2, _, _, _ = ops.forward(g, torch.from_numpy(x).to(dev).reshape(B * n, 3 + H), _tp(P, dev),
                               ops.step_sizes(ops.time_grid(4, 0.5)))
     assert _rel(S2.cpu().numpy(), So[..., 0]) <= RTOL
+
+
+def test_sir_large_state_paths(dev):
+    """n = 100 000 nodes: the trajectory state no longer fits a workgroup's LDS (global-memory state path);
+    n = 60 000 in coin mode needs > 64 KB of dynamic LDS.  Both bit-exact against the oracle."""
+    import gnode_oracle as O
+    import oracle_c as OC
+    from gnode.graph import DeviceGraph
+    from gnode.ode_nn import sir_counts, sir_counts_coins
+    n = 100_000
+    rp, ci, _ = O.er_graph(n, 300_000, seed=8)
+    g = DeviceGraph(rp, ci)
+    got = sir_counts(g, [5, 77, 4242], 0.35, 0.2, 24, 8, rng_seed=99).cpu().numpy().astype(np.uint32)
+    assert np.array_equal(got, OC.sir_philox(n, rp, ci, [5, 77, 4242], 0.35, 0.2, 24, 8, rng_seed=99))
+    n2 = 60_000
+    _, _, e2 = O.er_graph(n2, 150_000, seed=9)
+    table = O.edge_table(e2)
+    coins = np.random.default_rng(0).random(3_000_000)
+    S, I, R, used, _ = O.sir_coins(n2, table, [1, 2, 3], 0.4, 0.3, 2, 6, coins)
+    cnt, used_gpu = sir_counts_coins(n2, table, [1, 2, 3], 0.4, 0.3, 2, 6, coins[:used + 10])
+    c = cnt.cpu().numpy().astype(np.float64)
+    assert used_gpu == used and np.array_equal(c[0][None], S) and np.array_equal(c[1][None], I) and np.array_equal(c[2][None], R)
