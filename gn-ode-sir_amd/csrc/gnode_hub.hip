@@ -5,7 +5,8 @@
 // graphs the reference actually ships: wiki-vote has a row of degree 1 065, epinions ~3 000, and a
 // single lane group walking such a row holds its whole workgroup for hundreds of microseconds
 // (measured on a Chung-Lu graph, 75k nodes / 1M edges, max degree 12 777: 2 244 us per Euler step
-// instead of 213).  So rows longer than HUB_T are taken out of the step kernels:
+// instead of 213).  So rows longer than HUB_T (96 edges: below that, the two extra launches per step cost
+// more than the ~24 dependent batches they save) are taken out of the step kernels:
 //
 //   graph build  rows with degree > HUB_T become "hubs"; their neighbour lists are cut into
 //                segments of <= 32 edges (uniform work items).
@@ -27,7 +28,7 @@
 #define HUB_SEG 32
 
 static int hub_threshold() {
-    static const int v = [] { const char* e = getenv("GNODE_HUB_T"); int t = e ? atoi(e) : 48; return t < 4 ? 4 : t; }();
+    static const int v = [] { const char* e = getenv("GNODE_HUB_T"); int t = e ? atoi(e) : 96; return t < 4 ? 4 : t; }();
     return v;
 }
 
