@@ -31,6 +31,27 @@ def _csr_from_edges(n, e):
     return a.indptr.astype(np.int32), a.indices.astype(np.int32)
 
 
+_GRAPH_CACHE: dict = {}
+
+
+def _device_graph_for(G):
+    """The label loop calls sir_torch once per (seed set, beta, gamma) on the SAME networkx graph
+    (ode_nn_ngraph_sim.py:360-368): build and upload its CSR once, not 200 times."""
+    import weakref
+    key = (id(G), G.number_of_nodes(), G.number_of_edges())
+    hit = _GRAPH_CACHE.get(key)
+    if hit is not None and hit[0]() is G:            # same live object, not a recycled id
+        return hit[1]
+    if len(_GRAPH_CACHE) >= 4:
+        _GRAPH_CACHE.pop(next(iter(_GRAPH_CACHE)))
+    dg = DeviceGraph(*_csr_from_edges(G.number_of_nodes(), _edge_arrays(G)))
+    try:
+        _GRAPH_CACHE[key] = (weakref.ref(G), dg)
+    except TypeError:                                # not weak-referenceable: do not cache
+        pass
+    return dg
+
+
 def sir_counts(graph: DeviceGraph, seed_set, beta, gamma, sims, T, rng_seed, sim_offset=0, device="cuda",
                counts: torch.Tensor | None = None) -> torch.Tensor:
     """Production Monte-Carlo on the GPU: uint32 (stored as int32 tensor) counts [3, T, n].
@@ -79,8 +100,8 @@ def sir_torch(G, seed_set, beta, gamma, sims=10000, T=20, rng_seed=None, coins=N
     switches to the bit-exact parity mode.
     """
     n = G.number_of_nodes()
-    e = _edge_arrays(G)
     if coins is not None:
+        e = _edge_arrays(G)
         table = np.empty((2 * e.shape[0], 2), dtype=np.int64)     # reference :32-38
         table[0::2, 0], table[0::2, 1] = e[:, 0], e[:, 1]
         table[1::2, 0], table[1::2, 1] = e[:, 1], e[:, 0]
@@ -88,8 +109,7 @@ def sir_torch(G, seed_set, beta, gamma, sims=10000, T=20, rng_seed=None, coins=N
     else:
         if rng_seed is None:
             rng_seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
-        graph = DeviceGraph(*_csr_from_edges(n, e))
-        counts = sir_counts(graph, seed_set, beta, gamma, sims, T, rng_seed)
+        counts = sir_counts(_device_graph_for(G), seed_set, beta, gamma, sims, T, rng_seed)
     c = counts.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     c = c.astype(np.float64)
     return c[0][None], c[1][None], c[2][None]

@@ -75,11 +75,10 @@ def load_SIR_labels(dataset, path_to_save, G, I_indices, beta, gamma, sim, maxTi
         S, I, R = sir_torch(G, I_indices, beta, gamma, sim, maxTime)
         out = (S[0] / sim, I[0] / sim, R[0] / sim)
     else:
-        from .graph import DeviceGraph
-        from .ode_nn import _csr_from_edges, _edge_arrays, sir_counts
+        from .ode_nn import _device_graph_for, sir_counts
         seed = torch.randint(0, 2**62, (1,), dtype=torch.int64).to(dev)
         torch.distributed.broadcast(seed, src=0)
-        graph = DeviceGraph(*_csr_from_edges(G.number_of_nodes(), _edge_arrays(G)))
+        graph = _device_graph_for(G)
         lo, hi = sharding.shard_range(sim, rank, world)
         counts = sir_counts(graph, I_indices, beta, gamma, hi - lo, maxTime, int(seed.item()), sim_offset=lo)
         sharding.allreduce_counts(counts)
