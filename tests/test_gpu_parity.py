@@ -472,3 +472,46 @@ def test_sir_large_state_paths(dev):
     cnt, used_gpu = sir_counts_coins(n2, table, [1, 2, 3], 0.4, 0.3, 2, 6, coins[:used + 10])
     c = cnt.cpu().numpy().astype(np.float64)
     assert used_gpu == used and np.array_equal(c[0][None], S) and np.array_equal(c[1][None], I) and np.array_equal(c[2][None], R)
+
+
+def test_c_abi_standalone_host(tmp_path, dev):
+    """The boundary is a C ABI: a C++ host with no Python/torch in the process builds against include/gnode.h,
+    links libgnode_hip.so and gets the same numbers as the Python host path."""
+    import subprocess
+    import torch
+    from gnode import _lib, ops
+    from gnode.graph import DeviceGraph
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cabi_forward")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "cabi_forward.cpp"), "-L", libdir, "-lgnode_hip", "-o", exe], check=True)
+    n, B, H, n_steps = 1000, 2, 64, 9
+    r = subprocess.run([exe, str(n), str(B)], env=dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", "")),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = r.stdout.splitlines()[0]
+    sumS = float(line.split("sumS=")[1].split()[0]); sumI = float(line.split("sumI=")[1].split()[0])
+    # the same problem through the Python host (same LCG parameter fill)
+    s = np.uint32(12345)
+    def lcg():
+        nonlocal s
+        s = np.uint32((int(s) * 1664525 + 1013904223) & 0xFFFFFFFF)
+        return np.float32(int(s) >> 8) / np.float32(16777216.0)
+    fill = lambda cnt, sc: np.asarray([(lcg() * np.float32(2) - np.float32(1)) * np.float32(sc) for _ in range(cnt)], np.float32)
+    P = {"odefunc.linear.weight": fill(H * H, 0.125).reshape(H, H), "odefunc.linear.bias": fill(H, 0.125),
+         "linearS1.weight": fill(H, 1.0).reshape(H, 1), "linearS1.bias": fill(H, 1.0),
+         "linear3.weight": fill(4 * H, 0.125).reshape(4, H), "linear3.bias": fill(4, 0.125),
+         "linearS2.weight": fill(4, 0.5).reshape(1, 4), "linearS2.bias": fill(1, 0.5)}
+    rp, col = [0], []
+    for i in range(n):
+        col += sorted({(i - 7) % n, (i - 1) % n, (i + 1) % n, (i + 7) % n} - {i}); rp.append(len(col))
+    x = np.zeros((B * n, 3 + H), np.float32)
+    for r_ in range(B * n):
+        seeded = (r_ % n) == (r_ // n) * 3
+        x[r_, 0], x[r_, 1] = (0, 1) if seeded else (1, 0)
+        x[r_, 3], x[r_, 4] = np.float32(0.2) + np.float32(0.05) * np.float32(r_ // n), 0.1
+    g = DeviceGraph(np.asarray(rp, np.int32), np.asarray(col, np.int32))
+    S, I, R, _ = ops.forward(g, torch.from_numpy(x).to(dev), _tp(P, dev), np.full(n_steps, 0.5, np.float32))
+    assert abs(float(S.double().sum()) - sumS) <= 1e-3 * abs(sumS) * 1e-2 + 1e-2
+    assert abs(float(I.double().sum()) - sumI) <= 1e-3 * abs(sumI) * 1e-2 + 1e-2
