@@ -26,6 +26,10 @@ class ODEfunc(nn.Module):
         self.linear = nn.Linear(hidden1, hidden1)
         self.graph = DeviceGraph.from_scipy(A)     # CSR goes to HBM once, not once per RHS (:68-71)
 
+    def init_weights(self):
+        """reference :54-56 (defined, never called: the default nn.Linear init is what trains)."""
+        nn.init.xavier_normal_(self.linear.weight)
+
     def forward(self, t, x):
         """x [4*B*n, H] -> dx (reference :58-96).  t is unused there too."""
         with torch.no_grad():
@@ -49,6 +53,12 @@ class ODEBlock(nn.Module):
         self.ln = nn.LayerNorm(hidden1)             # unused in the reference forward
         self.linear3 = nn.Linear(hidden1, 4)
         self.linearS2 = nn.Linear(4, 1)
+
+    def init_weights(self):
+        """reference :139-146 (defined, never called)."""
+        nn.init.kaiming_normal_(self.linearS1.weight, mode="fan_in", nonlinearity="relu")
+        nn.init.kaiming_normal_(self.linear3.weight, mode="fan_in", nonlinearity="relu")
+        self.linearS2.weight.data.normal_(0, 1)
 
     def _params(self):
         return {"odefunc.linear.weight": self.odefunc.linear.weight, "odefunc.linear.bias": self.odefunc.linear.bias,

@@ -29,6 +29,10 @@ class ODEfunc(nn.Module):
         self._csr = [csr_arrays(A) for A in A_list]
         self._cache = {}
 
+    def init_weights(self):
+        """reference :57-58 (defined, never called)."""
+        self.linear.weight.data.normal_(0, 1)
+
     def graph_for(self, marker: torch.Tensor) -> DeviceGraph:
         """marker = x[3,:,2] (or x[:,5] of the 2-D input): one host sync per forward."""
         nz = torch.nonzero(marker).flatten()
@@ -64,6 +68,10 @@ class ODEBlock(nn.Module):
         self.ln = nn.LayerNorm(hidden1)
         self.linear3 = nn.Linear(hidden1, 4)
         self.linearS2 = nn.Linear(4, 1)
+
+    def init_weights(self):
+        """reference :121-122 (defined, never called)."""
+        self.linearS1.weight.data.normal_(0, 1)
 
     def _params(self):
         return {"odefunc.linear.weight": self.odefunc.linear.weight, "odefunc.linear.bias": self.odefunc.linear.bias,
