@@ -29,6 +29,8 @@ class _GNODEForward(torch.autograd.Function):
     def backward(ctx, gS, gI, gR):
         x2d, sol, *tensors = ctx.saved_tensors
         params = dict(zip(ctx.keys, tensors))
+        ref = next(g for g in (gS, gI, gR) if g is not None)          # an output the loss did not use has no gradient
+        gS, gI, gR = (torch.zeros_like(ref) if g is None else g for g in (gS, gI, gR))
         if not hasattr(ops, "backward"):
             raise NotImplementedError("GN-ODE adjoint backward is not built in this revision")
         grads = ops.backward(ctx.graph, x2d, params, ctx.dts, ctx.method, ctx.out_rows, sol,

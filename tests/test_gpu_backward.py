@@ -93,3 +93,20 @@ def test_autograd_training_step_reduces_loss(dev):
         losses.append(float(loss.detach()))
     assert all(p.grad is not None for k, p in model.named_parameters() if not k.endswith(("ln.weight", "ln.bias")))
     assert losses[-1] < losses[0]
+
+
+def test_loss_on_one_compartment_only(dev):
+    """A loss that uses only I (autograd hands None for the S and R gradients) still back-propagates."""
+    import torch
+    import scipy.sparse as sp
+    import gnode_oracle as O
+    from gnode.ode_nn_ngraph_sim import ODEfunc, ODEBlock
+    n, H = 50, 64
+    rp, ci, _ = O.er_graph(n, 150, seed=3)
+    A = sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n))
+    model = ODEBlock(4, 0.5, n, [0], H, ODEfunc(A, 0.2, 0.1, H, dev), dev).to(dev)
+    x = torch.from_numpy(O.make_samples(n, 2, H, seed=1)).to(dev)
+    S, I, R = model(x)
+    I.sum().backward()
+    g = model.odefunc.linear.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
