@@ -121,7 +121,7 @@ __device__ __forceinline__ void readout64(float4 yS, float4 yI, float4 yR, const
 template <bool FUSE, bool PRJ>
 __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                 long rows, int tiles_per_sample, long total_tiles,
-                                                float* __restrict__ Y, const float* __restrict__ ZI,
+                                                float* Y, const float* __restrict__ ZI,
                                                 float* __restrict__ ZI_next, const float* __restrict__ W,
                                                 const float* __restrict__ bias, const float* __restrict__ beta,
                                                 const float* __restrict__ gamma, float dt,
@@ -140,7 +140,11 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
     load_W_to_lds<false>(W, Wl);
     const float bias_l = bias[16 * w + (lane & 15)];
     const size_t slab = (size_t)rows * 64;
-    float* YS = Y; float* YI = Y + slab; float* YR = Y + 2 * slab;
+    // state in / state out: in place (inference), or trajectory point k -> k+1 when the caller keeps `sol`
+    // (then the trajectory IS the state and nothing is written twice)
+    const float* YS = Y; const float* YI = Y + slab; const float* YR = Y + 2 * slab;
+    float* Yo = out.sol ? out.sol : Y;
+    float* YSo = Yo; float* YIo = Yo + slab; float* YRo = Yo + 2 * slab;
 
     const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
 
@@ -215,9 +219,8 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
                 yr[p].x += dt * dR.x; yr[p].y += dt * dR.y; yr[p].z += dt * dR.z; yr[p].w += dt * dR.w;
             }
             if (valid[p]) {
-                st4s<NT>(YS + off[p], ys[p]); st4s<NT>(YI + off[p], yi[p]);
-                if (!PRJ) st4s<NT>(YR + off[p], yr[p]);
-                if (out.sol) { st4g(out.sol + off[p], ys[p]); st4g(out.sol + slab + off[p], yi[p]); st4g(out.sol + 2 * slab + off[p], yr[p]); }
+                st4s<NT>(YSo + off[p], ys[p]); st4s<NT>(YIo + off[p], yi[p]);
+                if (!PRJ) st4s<NT>(YRo + off[p], yr[p]);
             }
             if (out.S) {
                 float pS, pI, pR;

@@ -302,7 +302,7 @@ __device__ __forceinline__ float4 group_mlp(float4 x, const float* __restrict__ 
 
 template <int LPR>
 __global__ __launch_bounds__(256) void k_step_generic(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
-                                                      long rows, int H, float* __restrict__ Y,
+                                                      long rows, int H, float* Y,
                                                       const float* __restrict__ ZI, float* __restrict__ ZI_next,
                                                       const float* __restrict__ W, const float* __restrict__ bias,
                                                       const float* __restrict__ beta, const float* __restrict__ gamma,
@@ -337,9 +337,9 @@ __global__ __launch_bounds__(256) void k_step_generic(const int* __restrict__ ro
     yS.x += dt * dS.x; yS.y += dt * dS.y; yS.z += dt * dS.z; yS.w += dt * dS.w;
     yI.x += dt * dI.x; yI.y += dt * dI.y; yI.z += dt * dI.z; yI.w += dt * dI.w;
     yR.x += dt * dR.x; yR.y += dt * dR.y; yR.z += dt * dR.z; yR.w += dt * dR.w;
-    if (active) {
-        st4(Y + off, yS); st4(Y + slab + off, yI); st4(Y + 2 * slab + off, yR);
-        if (out.sol) { st4(out.sol + off, yS); st4(out.sol + slab + off, yI); st4(out.sol + 2 * slab + off, yR); }
+    if (active) {                                 // in place, or trajectory point k -> k+1 (the trajectory is the state)
+        float* Yo = out.sol ? out.sol : Y;
+        st4(Yo + off, yS); st4(Yo + slab + off, yI); st4(Yo + 2 * slab + off, yR);
     }
     if (out.S) {
         float pS, pI, pR;
@@ -653,17 +653,21 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         const float dt = dt_host[k];
         slot = out_slot(k + 1);
         float* sol_next = sol ? sol + (size_t)(k + 1) * 4 * slab : nullptr;
+        // with a trajectory the fused kernels read point k and write point k+1 (no separate state copy)
+        float* Ycur = (sol && (h64 || (method == 0 && H <= 128))) ? sol + (size_t)k * 4 * slab : Y;
         if (h64) {
             Step64Out out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
                              slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
             const bool sampled = prof_begin(0, st);
-            if (int e = gn_launch_step64(g, rows, Y, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,
+            if (int e = gn_launch_step64(g, rows, Ycur, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,
                                          gamma, dt, p, PR, out, fuse_zi, st))
                 return e;
             if (sampled) prof_mark(0, st);
             if (fuse_zi) std::swap(zi_cur, zi_nxt);
             else if (k + 1 < n_steps)
-                if (int e = launch_mlp(Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
+                if (int e = launch_mlp((sol_next ? sol_next : Y) + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur,
+                                       rows, H, st))
+                    return e;
         } else if (method == 0 && H <= 128) {
             // generic H: one fused launch per step (gather + both node MLPs as lane-group mat-vecs)
             StepOut out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
@@ -679,7 +683,7 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
                     GN_HIP(hipFuncSetAttribute((const void*)k_step_generic<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     attr_set = true;
                 }
-                hipLaunchKernelGGL(k_step_generic<LPR>, grid, dim3(256), lds, st, g->rowptr, g->col, g->n, (long)rows, H, Y, zi_cur,
+                hipLaunchKernelGGL(k_step_generic<LPR>, grid, dim3(256), lds, st, g->rowptr, g->col, g->n, (long)rows, H, Ycur, zi_cur,
                                    zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma, dt, p->linear3_weight,
                                    p->linear3_bias, p->linearS2_weight, p->linearS2_bias, out, g->hubidx, AIhub, g->n_hub);
             });
