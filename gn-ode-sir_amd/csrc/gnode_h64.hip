@@ -244,6 +244,193 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
     }
 }
 
+// --------------------------------------------------------------------------- k_tiny64: whole integration in ONE launch
+// Graphs whose per-sample state fits a workgroup's LDS (n <= 96 nodes at H = 64: karate, dolphins -- the
+// reference's shipped experiment is karate with batch size 1) are launch-latency bound with one launch per
+// step (~7 us each).  Samples of a batch never interact (block-diagonal adjacency), so one workgroup owns one
+// sample for ALL Euler steps: Y_S, Y_I, (Y_R | w3.Y_R) and both Z_I generations live in LDS, the gather reads
+// LDS, W^T stays staged, and the only global traffic is the outputs (and the trajectory when training).
+struct TinySched {
+    float dt[128];
+    short slot[128];      // output slot of grid point k+1, or -1
+    int n_steps;
+};
+
+// (start, end, first 16 column ids) of a row are loop-invariant across the Euler steps: the caller keeps them in
+// registers, so a step's gather touches global memory only for rows longer than 16 edges.
+__device__ __forceinline__ float4 gather_row_lds(const int* __restrict__ col, const float* __restrict__ Zl, int start, int end,
+                                                 int first16, int sub) {
+    float4 acc = zero4();
+    for (int e0 = start; e0 < end; e0 += 16) {
+        const int cnt = min(16, end - e0);
+        const int mine = (e0 == start) ? first16 : ((sub < cnt) ? col[e0 + sub] : 0);
+#define GN_L1(J)                                                                                  \
+        if (J < cnt) {                                                                            \
+            const float4 v = *reinterpret_cast<const float4*>(Zl + row_bcast<J>(mine) * TS + 4 * sub); \
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;                               \
+        }
+        GN_L1(0) GN_L1(1) GN_L1(2) GN_L1(3) GN_L1(4) GN_L1(5) GN_L1(6) GN_L1(7)
+        GN_L1(8) GN_L1(9) GN_L1(10) GN_L1(11) GN_L1(12) GN_L1(13) GN_L1(14) GN_L1(15)
+#undef GN_L1
+    }
+    return acc;
+}
+
+// One workgroup = nt x 256 threads: tile t of the sample is served by waves 4t .. 4t+3, all tiles advance together.
+template <bool PRJ>
+__global__ __launch_bounds__(768) void k_tiny64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+                                                long rows, const float* __restrict__ Y0, const float* __restrict__ ZI0,
+                                                const float* __restrict__ PR0, const float* __restrict__ W,
+                                                const float* __restrict__ bias, const float* __restrict__ beta,
+                                                const float* __restrict__ gamma, TinySched sched,
+                                                const float* __restrict__ w3, const float* __restrict__ b3,
+                                                const float* __restrict__ w2, const float* __restrict__ b2,
+                                                float* __restrict__ So, float* __restrict__ Io, float* __restrict__ Ro,
+                                                float* __restrict__ sol) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nt = (n + TILE_ROWS - 1) / TILE_ROWS, tile_f = TILE_ROWS * TS;
+    float* Wl = lds;
+    float* T2all = Wl + 64 * TS;                  // one scratch tile per row tile
+    float* YS = T2all + nt * tile_f;
+    float* YI = YS + nt * tile_f;
+    float* ZA = YI + nt * tile_f;
+    float* ZB = ZA + nt * tile_f;
+    float* YR = ZB + nt * tile_f;                 // PRJ: [nt*32][4] projections, else [nt*32][TS] full rows
+    const int t = threadIdx.x >> 8;               // this thread's row tile
+    const int tid = threadIdx.x & 255;
+    const int lane = tid & 63, w = tid >> 6, g = lane >> 4, sub = lane & 15;
+    float* T2 = T2all + t * tile_f;
+    const long base = (long)blockIdx.x * n;
+    const size_t slab = (size_t)rows * 64;
+    if (t == 0) load_W_to_lds<false>(W, Wl);      // threads 0..255 (threadIdx.x == tid there)
+    const float bias_l = bias[16 * w + (lane & 15)];
+    int lrow[2]; bool valid[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        lrow[p] = t * TILE_ROWS + w * 8 + 4 * p + g;
+        valid[p] = lrow[p] < n;
+        const size_t off = (size_t)(base + lrow[p]) * 64 + 4 * sub;
+        *reinterpret_cast<float4*>(YS + lrow[p] * TS + 4 * sub) = valid[p] ? ld4g(Y0 + off) : zero4();
+        *reinterpret_cast<float4*>(YI + lrow[p] * TS + 4 * sub) = valid[p] ? ld4g(Y0 + slab + off) : zero4();
+        *reinterpret_cast<float4*>(ZA + lrow[p] * TS + 4 * sub) = valid[p] ? ld4g(ZI0 + off) : zero4();
+        if (PRJ) { if (sub == 0) *reinterpret_cast<float4*>(YR + lrow[p] * 4) = valid[p] ? ld4g(PR0 + (size_t)(base + lrow[p]) * 4) : zero4(); }
+        else *reinterpret_cast<float4*>(YR + lrow[p] * TS + 4 * sub) = valid[p] ? ld4g(Y0 + 2 * slab + off) : zero4();
+    }
+    float nb[2] = {0.f, 0.f}, gm[2] = {0.f, 0.f};
+    int e_lo[2] = {0, 0}, e_hi[2] = {0, 0}, first16[2] = {0, 0};
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        if (valid[p]) {
+            nb[p] = -beta[base + lrow[p]]; gm[p] = gamma[base + lrow[p]];
+            e_lo[p] = rowptr[lrow[p]]; e_hi[p] = rowptr[lrow[p] + 1];
+            first16[p] = (e_lo[p] + sub < e_hi[p]) ? col[e_lo[p] + sub] : 0;
+        }
+    __syncthreads();
+    float* Zc = ZA; float* Zn = ZB;
+    for (int k = 0; k < sched.n_steps; ++k) {
+        const float dt = sched.dt[k];
+        const int slot = sched.slot[k];
+        float* solk = sol ? sol + (size_t)(k + 1) * 4 * slab : nullptr;
+        float4 ai[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ai[p] = gather_row_lds(col, Zc, e_lo[p], e_hi[p], first16[p], sub);
+        mfma_tile<true>(YS + t * tile_f, Wl, T2, bias_l, w, lane);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int lr = lrow[p] - t * TILE_ROWS;
+            const float4 zs = *reinterpret_cast<const float4*>(T2 + lr * TS + 4 * sub);
+            const float4 zi = *reinterpret_cast<const float4*>(Zc + lrow[p] * TS + 4 * sub);
+            float4 ys = *reinterpret_cast<const float4*>(YS + lrow[p] * TS + 4 * sub);
+            float4 yi = *reinterpret_cast<const float4*>(YI + lrow[p] * TS + 4 * sub);
+            float4 dS, dI, dR;
+            dS.x = nb[p] * (ai[p].x * zs.x); dS.y = nb[p] * (ai[p].y * zs.y); dS.z = nb[p] * (ai[p].z * zs.z); dS.w = nb[p] * (ai[p].w * zs.w);
+            dR.x = gm[p] * zi.x; dR.y = gm[p] * zi.y; dR.z = gm[p] * zi.z; dR.w = gm[p] * zi.w;
+            dI.x = -dS.x - dR.x; dI.y = -dS.y - dR.y; dI.z = -dS.z - dR.z; dI.w = -dS.w - dR.w;
+            ys.x += dt * dS.x; ys.y += dt * dS.y; ys.z += dt * dS.z; ys.w += dt * dS.w;
+            yi.x += dt * dI.x; yi.y += dt * dI.y; yi.z += dt * dI.z; yi.w += dt * dI.w;
+            *reinterpret_cast<float4*>(YS + lrow[p] * TS + 4 * sub) = ys;
+            *reinterpret_cast<float4*>(YI + lrow[p] * TS + 4 * sub) = yi;
+            float4 yr = zero4();
+            float prj[4] = {0.f, 0.f, 0.f, 0.f};
+            if (PRJ) {
+                const float4 pr = *reinterpret_cast<const float4*>(YR + lrow[p] * 4);
+                float4 w3r[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w3r[q] = ld4g(w3 + q * 64 + 4 * sub);
+                prj[0] = pr.x + dt * (gm[p] * row_sum16(fmaf(w3r[0].x, zi.x, fmaf(w3r[0].y, zi.y, fmaf(w3r[0].z, zi.z, w3r[0].w * zi.w)))));
+                prj[1] = pr.y + dt * (gm[p] * row_sum16(fmaf(w3r[1].x, zi.x, fmaf(w3r[1].y, zi.y, fmaf(w3r[1].z, zi.z, w3r[1].w * zi.w)))));
+                prj[2] = pr.z + dt * (gm[p] * row_sum16(fmaf(w3r[2].x, zi.x, fmaf(w3r[2].y, zi.y, fmaf(w3r[2].z, zi.z, w3r[2].w * zi.w)))));
+                prj[3] = pr.w + dt * (gm[p] * row_sum16(fmaf(w3r[3].x, zi.x, fmaf(w3r[3].y, zi.y, fmaf(w3r[3].z, zi.z, w3r[3].w * zi.w)))));
+                if (sub == 0) *reinterpret_cast<float4*>(YR + lrow[p] * 4) = make_float4(prj[0], prj[1], prj[2], prj[3]);
+            } else {
+                yr = *reinterpret_cast<const float4*>(YR + lrow[p] * TS + 4 * sub);
+                yr.x += dt * dR.x; yr.y += dt * dR.y; yr.z += dt * dR.z; yr.w += dt * dR.w;
+                *reinterpret_cast<float4*>(YR + lrow[p] * TS + 4 * sub) = yr;
+            }
+            if (solk && valid[p]) {
+                const size_t off = (size_t)(base + lrow[p]) * 64 + 4 * sub;
+                st4g(solk + off, ys); st4g(solk + slab + off, yi); st4g(solk + 2 * slab + off, yr);
+            }
+            if (slot >= 0) {
+                float pS, pI, pR;
+                readout64<PRJ>(ys, yi, yr, prj, sub, w3, b3, w2, b2, pS, pI, pR);
+                if (valid[p] && sub == 0) {
+                    const size_t o = (size_t)slot * rows + base + lrow[p];
+                    So[o] = pS; Io[o] = pI; Ro[o] = pR;
+                }
+            }
+        }
+        __syncthreads();                           // Y_I tile complete, T2 free
+        mfma_tile<true>(YI + t * tile_f, Wl, T2, bias_l, w, lane);   // Z_I of the next step
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            *reinterpret_cast<float4*>(Zn + lrow[p] * TS + 4 * sub) =
+                *reinterpret_cast<const float4*>(T2 + (lrow[p] - t * TILE_ROWS) * TS + 4 * sub);
+        __syncthreads();                           // every tile's Z_I' is in place before the next gather
+        float* tmp = Zc; Zc = Zn; Zn = tmp;
+    }
+}
+
+size_t gn_tiny64_lds_bytes(int n, bool prj) {
+    const int nt = (n + TILE_ROWS - 1) / TILE_ROWS;
+    const size_t tile_f = (size_t)TILE_ROWS * TS;
+    return sizeof(float) * ((size_t)64 * TS + 5 * nt * tile_f + (prj ? (size_t)nt * TILE_ROWS * 4 : nt * tile_f));
+}
+
+// true when the whole integration of one sample fits a workgroup (and the schedule fits the kernel arguments)
+bool gn_tiny64_ok(int n, int n_steps, int n_out, bool prj) {
+    static const bool on = [] { const char* e = getenv("GNODE_TINY"); return !(e && e[0] == '0'); }();
+    return on && n_steps >= 1 && n_steps <= 128 && n_out < 32768 && n <= 3 * TILE_ROWS &&
+           gn_tiny64_lds_bytes(n, prj) <= 160 * 1024;
+}
+
+int gn_launch_tiny64(const gnode_graph_s* g, long rows, const float* Y0, const float* ZI0, const float* PR0, const float* W,
+                     const float* bias, const float* beta, const float* gamma, const float* dt_host, const int* slot_host,
+                     int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol, hipStream_t st) {
+    TinySched sched;
+    sched.n_steps = n_steps;
+    for (int k = 0; k < n_steps; ++k) { sched.dt[k] = dt_host[k]; sched.slot[k] = (short)slot_host[k]; }
+    const bool prj = PR0 != nullptr;
+    const size_t lds = gn_tiny64_lds_bytes(g->n, prj);
+    const unsigned B = (unsigned)(rows / g->n);
+    const unsigned threads = 256u * (unsigned)((g->n + TILE_ROWS - 1) / TILE_ROWS);
+    if (prj) {
+        static bool attr = false;
+        if (!attr) { GN_HIP(hipFuncSetAttribute((const void*)k_tiny64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        hipLaunchKernelGGL(k_tiny64<true>, dim3(B), dim3(threads), lds, st, g->rowptr, g->col, g->n, rows, Y0, ZI0, PR0, W, bias, beta,
+                           gamma, sched, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, S, I, R, sol);
+    } else {
+        static bool attr = false;
+        if (!attr) { GN_HIP(hipFuncSetAttribute((const void*)k_tiny64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        hipLaunchKernelGGL(k_tiny64<false>, dim3(B), dim3(threads), lds, st, g->rowptr, g->col, g->n, rows, Y0, ZI0, PR0, W, bias, beta,
+                           gamma, sched, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, S, I, R, sol);
+    }
+    GN_LAUNCH_CHECK();
+    return 0;
+}
+
 // PR0[r][k] = w3[k] . Y_R[r]  (once per forward, PRJ mode)
 __global__ __launch_bounds__(256) void k_init_pr64(const float* __restrict__ YR, const float* __restrict__ w3,
                                                    float* __restrict__ PR, long rows) {

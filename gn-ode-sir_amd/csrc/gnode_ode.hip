@@ -649,6 +649,21 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         if (PR) if (int e = gn_launch_init_pr64(Y + 2 * slab, p->linear3_weight, PR, rows, st)) return e;
     }
 
+    if (h64 && fuse_zi && gn_tiny64_ok(g->n, n_steps, out_rows_host ? n_out : G, PR != nullptr)) {
+        // tiny graphs: the whole integration in one launch (one workgroup per sample, state in LDS)
+        int slots[128];
+        for (int k = 0; k < n_steps; ++k) slots[k] = out_slot(k + 1);
+        if (int e = gn_launch_tiny64(g, rows, Y, zi_cur, PR, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma,
+                                     dt_host, slots, n_steps, p, S, I, R, sol, st))
+            return e;
+        if (sol) {
+            const size_t slab4 = slab / 4;
+            hipLaunchKernelGGL(k_fill_bg, dim3((unsigned)std::min<size_t>((slab4 + 255) / 256, 2048)), dim3(256), 0, st, sol, slab4, G);
+            GN_LAUNCH_CHECK();
+        }
+        return 0;
+    }
+
     for (int k = 0; k < n_steps; ++k) {
         const float dt = dt_host[k];
         slot = out_slot(k + 1);
