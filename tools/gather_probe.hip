@@ -53,17 +53,18 @@ static void run(const float* T, long table_rows, long n_groups, int deg, float* 
     hipFree(idx);
 }
 
-int main() {
-    const long table_rows = 600000;            // 8 samples x 75k rows x 256 B = 154 MB
+int main(int argc, char** argv) {
     const long n_groups = 600000;              // one gathered row-sum per group
     const int deg = 12;
     float *T, *out;
-    hipMalloc(&T, (size_t)table_rows * 256);
+    hipMalloc(&T, (size_t)600000 * 256);
     hipMalloc(&out, (size_t)n_groups * 256);
-    hipMemset(T, 0, (size_t)table_rows * 256);
-    run<1>(T, table_rows, n_groups, deg, out);
-    run<2>(T, table_rows, n_groups, deg, out);
-    run<4>(T, table_rows, n_groups, deg, out);
-    run<8>(T, table_rows, n_groups, deg, out);
+    hipMemset(T, 0, (size_t)600000 * 256);
+    const long sizes[3] = {600000, 150000, 75000};   // 154 MB (8 samples' Z_I), 38 MB, 19 MB (one sample)
+    for (long table_rows : sizes) {
+        printf("table %.0f MB\n", table_rows * 256 / 1e6);
+        run<1>(T, table_rows, n_groups, deg, out);
+        run<8>(T, table_rows, n_groups, deg, out);
+    }
     return 0;
 }
