@@ -110,3 +110,28 @@ def test_loss_on_one_compartment_only(dev):
     I.sum().backward()
     g = model.odefunc.linear.weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+
+
+def test_forward_and_backward_are_bitwise_reproducible(dev):
+    """No float atomics anywhere on the path: two runs on the same inputs give identical bits
+    (the reference's GPU scatter_add_ is order-dependent, quirk Q7)."""
+    import torch
+    import gnode_oracle as O
+    from gnode import ops
+    from gnode.graph import DeviceGraph
+    n, B, H = 2000, 3, 64
+    rp, ci, _ = O.chung_lu_graph(n, 20000, seed=4)          # hubs included
+    P = {k: torch.from_numpy(v).to(dev) for k, v in O.init_params(H, seed=1).items()}
+    x = torch.from_numpy(O.make_samples(n, B, H, seed=2)).to(dev).reshape(B * n, 3 + H)
+    g = DeviceGraph(rp, ci)
+    dts = ops.step_sizes(ops.time_grid(6, 0.5))
+    gs = [torch.randn(len(dts) + 1, B * n, device=dev) for _ in range(3)]
+    runs = []
+    for _ in range(2):
+        S, I, R, sol = ops.forward(g, x, P, dts, want_sol=True)
+        grads = ops.backward(g, x, P, dts, "euler", None, sol, *gs)
+        runs.append((S.clone(), I.clone(), R.clone(), {k: v.clone() for k, v in grads.items()}))
+    for a, b in zip(runs[0][:3], runs[1][:3]):
+        assert torch.equal(a, b)
+    for k in runs[0][3]:
+        assert torch.equal(runs[0][3][k], runs[1][3][k]), k
