@@ -120,7 +120,9 @@ def main():
 
     # ---- A3(+A4 restated): ODEBlock.forward (single graph)
     for gname, B, H, maxTime, deltaT in [("karate", 2, 64, 20, 0.5), ("loops40", 3, 8, 6, 0.5),
-                                         ("er200", 2, 64, 5, 0.5), ("karate", 1, 16, 3, 0.25)]:
+                                         ("er200", 2, 64, 5, 0.5), ("karate", 1, 16, 3, 0.25),
+                                         ("karate", 2, 64, 30, 0.5),      # the headline horizon: 59 Euler steps
+                                         ("loops40", 2, 64, 12, 1.0)]:    # deltaT = 1: every grid point is kept
         G = graphs[gname]
         A = nx.adjacency_matrix(G)
         n = A.shape[0]
