@@ -515,3 +515,44 @@ def test_c_abi_standalone_host(tmp_path, dev):
     S, I, R, _ = ops.forward(g, torch.from_numpy(x).to(dev), _tp(P, dev), np.full(n_steps, 0.5, np.float32))
     assert abs(float(S.double().sum()) - sumS) <= 1e-3 * abs(sumS) * 1e-2 + 1e-2
     assert abs(float(I.double().sum()) - sumI) <= 1e-3 * abs(sumI) * 1e-2 + 1e-2
+
+
+def test_randomized_configurations(dev):
+    """Seeded sweep over the corners that fixed cases miss: node counts around tile multiples (31..33, 63..65,
+    95..97: the single-launch path's limits), degrees around the hub threshold (96/97), isolated nodes, every H
+    class, arbitrary out_rows subsets, with and without the trajectory, Euler and RK4."""
+    import torch
+    import gnode_oracle as O
+    from gnode import ops
+    from gnode.graph import DeviceGraph
+    rng = np.random.default_rng(2024)
+    n_choices = [2, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 130, 257]
+    for case in range(28):
+        n = int(rng.choice(n_choices))
+        H = int(rng.choice([4, 8, 16, 24, 32, 64, 64, 64]))
+        B = int(rng.integers(1, 4))
+        maxTime = int(rng.integers(2, 6))
+        deltaT = float(rng.choice([0.25, 0.5, 1.0]))
+        method = "rk4" if case % 7 == 6 else "euler"
+        m = int(rng.integers(0, 3 * n))
+        edges = [(int(a), int(b)) for a, b in rng.integers(0, n, size=(m, 2))]
+        if n >= 130 and case % 2 == 0:                      # a hub right at / above the threshold
+            d = 96 if case % 4 == 0 else 97
+            edges += [(0, j) for j in range(1, d + 1)]
+        rp, ci = O.csr_from_edges(n, edges) if edges else (np.zeros(n + 1, np.int32), np.zeros(0, np.int32))
+        P = O.init_params(H, seed=case)
+        x = O.make_samples(n, B, H, seed=case, n_seeds=1)
+        G = len(O.time_grid(maxTime, deltaT))
+        sel = np.sort(rng.choice(G, size=int(rng.integers(1, G + 1)), replace=False)).astype(np.int32) if case % 3 else None
+        want_sol = bool(case % 2)
+        g = DeviceGraph(rp, ci)
+        S, I, R, sol = ops.forward(g, torch.from_numpy(x).to(dev).reshape(B * n, 3 + H), _tp(P, dev),
+                                   ops.step_sizes(O.time_grid(maxTime, deltaT)), method, sel, want_sol)
+        So, Io, Ro, sol_o = O.odeblock_forward_single(x, P, rp, ci, maxTime, deltaT, method=method, return_sol=True)
+        idx = np.arange(G) if sel is None else sel
+        tag = f"case {case}: n={n} H={H} B={B} T={maxTime} dT={deltaT} {method} sel={None if sel is None else sel.tolist()} sol={want_sol}"
+        for got, w in zip((S, I, R), (So, Io, Ro)):
+            assert tuple(got.shape) == (len(idx), B * n), tag
+            assert _rel(got.cpu().numpy(), w[idx, :, 0]) <= RTOL, tag
+        if want_sol:
+            assert _rel(sol.cpu().numpy(), sol_o) <= RTOL, tag
