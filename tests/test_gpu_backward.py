@@ -25,6 +25,8 @@ def _rel(a, b):
     (150, 700, 2, 64, 6, 0.5, True),       # fused get_sir_t_nodes subsample: grads only at kept rows
     (90, 300, 2, 32, 4, 0.25, False),
     (40, 100, 1, 128, 3, 0.5, False),
+    (40, 120, 2, 64, 5, 0.5, False),       # n <= 64: the forward that feeds this backward is the single-launch kernel
+    (64, 200, 1, 64, 4, 0.5, True),
 ])
 def test_param_grads_vs_oracle(n, m, B, H, maxTime, deltaT, sub, dev, skewed=False):
     import torch
