@@ -15,6 +15,10 @@
 //     P4  (FUSE) Z_I of the NEXT step from the freshly updated Y_I rows, again on
 //         the matrix cores, so the separate node-MLP launch disappears and
 //         Y_S / Y_I are read once per step.
+//     PRJ (inference): the R compartment is carried as w3 . Y_R (4 floats per row) -- it only
+//         feeds the read-out, whose first layer is linear.
+//     Rows longer than the hub threshold arrive pre-summed from gnode_hub.hip.
+//   k_tiny64<PRJ>    graphs that fit one workgroup's LDS: ALL Euler steps in one launch.
 //   k_mlp64          the same MFMA tile engine alone (RHS API, step 0, RK4 stages).
 //
 // Reference semantics: ode_nn_ngraph_sim.py:58-96 (RHS), :168 (euler), :172-187 (head).
