@@ -28,6 +28,11 @@
 #include <algorithm>
 #include <cstdlib>
 
+template <bool NT>
+__device__ __forceinline__ float4 ld4so(const float* b, unsigned off) { return ld4s<NT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(b) + off)); }
+template <bool NT>
+__device__ __forceinline__ void st4so(float* b, unsigned off, float4 v) { st4s<NT>(reinterpret_cast<float*>(reinterpret_cast<char*>(b) + off), v); }
+
 // ---- pull-gather of one row by a 16-lane group ---------------------------------------
 // ascending-column accumulation order = the CPU scatter_add_ order of the reference.
 __device__ __forceinline__ float4 gather_row64(const int* __restrict__ rowptr, const int* __restrict__ col,
@@ -35,17 +40,18 @@ __device__ __forceinline__ float4 gather_row64(const int* __restrict__ rowptr, c
     float4 acc = zero4();
     int start = 0, end = 0;
     if (valid) { start = rowptr[node]; end = rowptr[node + 1]; }
+    const unsigned lane_b = 16u * sub;
     for (int e0 = start; e0 < end; e0 += 16) {
         const int cnt = min(16, end - e0);
-        const int mine = (sub < cnt) ? col[e0 + sub] : 0;
+        const unsigned mine = (sub < cnt) ? (unsigned)col[e0 + sub] * 256u : 0u;   // byte offset of the neighbour row
 #define GN_G4(J)                                                                               \
         if (J < cnt) {                                                                         \
-            const int c0 = row_bcast<J>(mine), c1 = row_bcast<J + 1>(mine);                    \
-            const int c2 = row_bcast<J + 2>(mine), c3 = row_bcast<J + 3>(mine);                \
-            float4 v0 = ld4g(ZI_base + (size_t)c0 * 64 + 4 * sub), v1 = zero4(), v2 = v1, v3 = v1; \
-            if (J + 1 < cnt) v1 = ld4g(ZI_base + (size_t)c1 * 64 + 4 * sub);                   \
-            if (J + 2 < cnt) v2 = ld4g(ZI_base + (size_t)c2 * 64 + 4 * sub);                   \
-            if (J + 3 < cnt) v3 = ld4g(ZI_base + (size_t)c3 * 64 + 4 * sub);                   \
+            const unsigned c0 = row_bcast<J>((int)mine), c1 = row_bcast<J + 1>((int)mine);     \
+            const unsigned c2 = row_bcast<J + 2>((int)mine), c3 = row_bcast<J + 3>((int)mine); \
+            float4 v0 = ld4o(ZI_base, c0 + lane_b), v1 = zero4(), v2 = v1, v3 = v1;            \
+            if (J + 1 < cnt) v1 = ld4o(ZI_base, c1 + lane_b);                                  \
+            if (J + 2 < cnt) v2 = ld4o(ZI_base, c2 + lane_b);                                  \
+            if (J + 3 < cnt) v3 = ld4o(ZI_base, c3 + lane_b);                                  \
             acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;                        \
             acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;                        \
             acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;                        \
@@ -118,12 +124,14 @@ __device__ __forceinline__ void readout64(float4 yS, float4 yI, float4 yR, const
     }
     const float m = fmaxf(qS, fmaxf(qI, qR));
     const float eS = __expf(qS - m), eI = __expf(qI - m), eR = __expf(qR - m);
-    const float inv = 1.0f / (eS + eI + eR);
+    const float inv = __builtin_amdgcn_rcpf(eS + eI + eR);
     pS = eS * inv; pI = eI * inv; pR = eR * inv;
 }
 
-template <bool FUSE, bool PRJ>
-__global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+// RPG = rows per 16-lane group and tile: 2 -> 32-row tiles, 4 workgroups per CU; 1 -> 16-row tiles, half the LDS
+// and far fewer live registers per wave, 6 workgroups per CU.
+template <bool FUSE, bool PRJ, int RPG>
+__global__ __launch_bounds__(256, (RPG == 2 ? 4 : 6)) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                 long rows, int tiles_per_sample, long total_tiles,
                                                 float* Y, const float* __restrict__ ZI,
                                                 float* __restrict__ ZI_next, const float* __restrict__ W,
@@ -138,8 +146,9 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
     constexpr bool NT = true;
     constexpr int XQ = 8;
     __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
-    __shared__ __attribute__((aligned(16))) float T[TILE_ROWS * TS];
-    __shared__ __attribute__((aligned(16))) float T2[TILE_ROWS * TS];
+    constexpr int TR = 16 * RPG;                  // rows per tile
+    __shared__ __attribute__((aligned(16))) float T[TR * TS];
+    __shared__ __attribute__((aligned(16))) float T2[TR * TS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
     load_W_to_lds<false>(W, Wl);
     const float bias_l = bias[16 * w + (lane & 15)];
@@ -150,7 +159,9 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
     float* Yo = out.sol ? out.sol : Y;
     float* YSo = Yo; float* YIo = Yo + slab; float* YRo = Yo + 2 * slab;
 
-    const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
+    int lr[RPG];
+#pragma unroll
+    for (int p = 0; p < RPG; ++p) lr[p] = w * 4 * RPG + 4 * p + g;
 
     // Tile walk.  XQ > 1: the tile range is cut into XQ contiguous queues (with 8 samples per launch a queue
     // is one sample) and workgroup i serves queue i % XQ.  Workgroups are dealt round-robin over the 8 XCDs,
@@ -159,43 +170,47 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
     const int xq = (XQ > 1 && gridDim.x % XQ == 0 && total_tiles >= 4 * XQ) ? XQ : 1;
     const int q = blockIdx.x % xq;
     const long q_lo = total_tiles * q / xq, q_hi = total_tiles * (q + 1) / xq;
-    for (long t = q_lo + blockIdx.x / xq; t < q_hi; t += gridDim.x / xq) {
-        const long b = t / tiles_per_sample;
-        const int tile = (int)(t - b * tiles_per_sample);
+    // (sample, tile) advance incrementally: no 64-bit division in the tile loop
+    const long t_first = q_lo + blockIdx.x / xq;
+    long b = t_first / tiles_per_sample;
+    int tile = (int)(t_first - b * tiles_per_sample);
+    const int t_stride = gridDim.x / xq;
+    for (long t = t_first; t < q_hi; t += t_stride, tile += t_stride) {
+        while (tile >= tiles_per_sample) { tile -= tiles_per_sample; ++b; }
         const long base = b * n;
-        int node[2]; bool valid[2]; size_t off[2];
-        float4 ys[2], ai[2], yi[2], yr[2], zi[2];
+        int node[RPG]; bool valid[RPG]; unsigned off[RPG];       // off: BYTE offset of this lane's 16 B inside a slab
+        float4 ys[RPG], ai[RPG], yi[RPG], yr[RPG], zi[RPG];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            node[p] = tile * TILE_ROWS + lr[p];
+        for (int p = 0; p < RPG; ++p) {
+            node[p] = tile * TR + lr[p];
             valid[p] = node[p] < n;
-            off[p] = (size_t)(base + node[p]) * 64 + 4 * sub;
-            ys[p] = valid[p] ? ld4s<NT>(YS + off[p]) : zero4();
+            off[p] = (unsigned)(base + node[p]) * 256u + 16u * sub;
+            ys[p] = valid[p] ? ld4so<NT>(YS, off[p]) : zero4();
         }
         // -------- P1: stage Y_S, issue own-row loads, gather
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < RPG; ++p) {
             *reinterpret_cast<float4*>(T + lr[p] * TS + 4 * sub) = ys[p];
-            yi[p] = valid[p] ? ld4s<NT>(YI + off[p]) : zero4();
-            yr[p] = (!PRJ && valid[p]) ? ld4s<NT>(YR + off[p]) : zero4();
-            zi[p] = valid[p] ? ld4g(ZI + off[p]) : zero4();
+            yi[p] = valid[p] ? ld4so<NT>(YI, off[p]) : zero4();
+            yr[p] = (!PRJ && valid[p]) ? ld4so<NT>(YR, off[p]) : zero4();
+            zi[p] = valid[p] ? ld4o(ZI, off[p]) : zero4();
         }
         // (measured: gathering the two rows in lockstep with 8 loads in flight per lane is 25 % SLOWER --
         //  the memory system is already at its request-rate limit)
         // long rows ("hubs") were summed beforehand by the segment kernels of gnode_hub.hip
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < RPG; ++p) {
             const int hub = (hubidx && valid[p]) ? hubidx[node[p]] : -1;
-            if (hub >= 0) ai[p] = ld4g(AIhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+            if (hub >= 0) ai[p] = ld4o(AIhub, ((unsigned)b * (unsigned)n_hub + (unsigned)hub) * 256u + 16u * sub);
             else ai[p] = gather_row64(rowptr, col, ZI + (size_t)base * 64, node[p], valid[p], sub);
         }
         __syncthreads();
         // -------- P2: Z_S on the matrix cores
-        mfma_tile<true>(T, Wl, T2, bias_l, w, lane);
+        if (RPG == 2) mfma_tile<true>(T, Wl, T2, bias_l, w, lane); else mfma_tile16(T, Wl, T2, bias_l, w, lane);
         __syncthreads();
         // -------- P3: SIR derivative (ode_nn_ngraph_sim.py:75-77), Euler update, read-out
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < RPG; ++p) {
             const float4 zs = *reinterpret_cast<const float4*>(T2 + lr[p] * TS + 4 * sub);
             float nb = 0.f, gm = 0.f;
             if (valid[p]) { nb = -beta[base + node[p]]; gm = gamma[base + node[p]]; }
@@ -210,7 +225,7 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
                 // R only feeds the read-out, and its first layer is linear: carry w3 . Y_R (4 floats per row)
                 // instead of Y_R (64):  w3 . (Y_R + dt*gamma*Z_I) = w3 . Y_R + dt*gamma*(w3 . Z_I)
                 float4 pr = zero4();
-                if (valid[p]) pr = ld4g(PR + (size_t)(base + node[p]) * 4);
+                if (valid[p]) pr = ld4o(PR, (unsigned)(base + node[p]) * 16u);
                 float4 w3r[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) w3r[k] = ld4g(w3 + k * 64 + 4 * sub);   // L1-resident, shared with the read-out
@@ -218,13 +233,13 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
                 prj[1] = pr.y + dt * (gm * row_sum16(fmaf(w3r[1].x, zi[p].x, fmaf(w3r[1].y, zi[p].y, fmaf(w3r[1].z, zi[p].z, w3r[1].w * zi[p].w)))));
                 prj[2] = pr.z + dt * (gm * row_sum16(fmaf(w3r[2].x, zi[p].x, fmaf(w3r[2].y, zi[p].y, fmaf(w3r[2].z, zi[p].z, w3r[2].w * zi[p].w)))));
                 prj[3] = pr.w + dt * (gm * row_sum16(fmaf(w3r[3].x, zi[p].x, fmaf(w3r[3].y, zi[p].y, fmaf(w3r[3].z, zi[p].z, w3r[3].w * zi[p].w)))));
-                if (valid[p] && sub == 0) st4g(PR + (size_t)(base + node[p]) * 4, make_float4(prj[0], prj[1], prj[2], prj[3]));
+                if (valid[p] && sub == 0) st4o(PR, (unsigned)(base + node[p]) * 16u, make_float4(prj[0], prj[1], prj[2], prj[3]));
             } else {
                 yr[p].x += dt * dR.x; yr[p].y += dt * dR.y; yr[p].z += dt * dR.z; yr[p].w += dt * dR.w;
             }
             if (valid[p]) {
-                st4s<NT>(YSo + off[p], ys[p]); st4s<NT>(YIo + off[p], yi[p]);
-                if (!PRJ) st4s<NT>(YRo + off[p], yr[p]);
+                st4so<NT>(YSo, off[p], ys[p]); st4so<NT>(YIo, off[p], yi[p]);
+                if (!PRJ) st4so<NT>(YRo, off[p], yr[p]);
             }
             if (out.S) {
                 float pS, pI, pR;
@@ -238,11 +253,11 @@ __global__ __launch_bounds__(256, 4) void k_step64(const int* __restrict__ rowpt
         if (FUSE) {
             // -------- P4: Z_I of the next step from the updated Y_I rows
             __syncthreads();
-            mfma_tile<true>(T, Wl, T2, bias_l, w, lane);
+            if (RPG == 2) mfma_tile<true>(T, Wl, T2, bias_l, w, lane); else mfma_tile16(T, Wl, T2, bias_l, w, lane);
             __syncthreads();
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-                if (valid[p]) st4g(ZI_next + off[p], *reinterpret_cast<const float4*>(T2 + lr[p] * TS + 4 * sub));
+            for (int p = 0; p < RPG; ++p)
+                if (valid[p]) st4o(ZI_next, off[p], *reinterpret_cast<const float4*>(T2 + lr[p] * TS + 4 * sub));
         }
         __syncthreads();   // T / T2 are rewritten by the next tile
     }
@@ -488,21 +503,27 @@ int gn_launch_mlp64(const float* X, const float* W, const float* b, float* Z, lo
 int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, float* ZI_next, const float* W,
                      const float* bias, const float* beta, const float* gamma, float dt, const gnode_params* p,
                      float* PR, Step64Out out, bool fuse, hipStream_t st) {
-    const int tps = (g->n + TILE_ROWS - 1) / TILE_ROWS;
+    GN_CHECK_ARG(rows < (1L << 24), "H=64 step kernel addresses rows with 32-bit byte offsets: rows=%ld >= 2^24 per launch "
+                 "(split the batch)", rows);
+    static const int rpg = [] { const char* e = getenv("GNODE_RPG"); return (e && e[0] == '1') ? 1 : 2; }();
+    const int tr = 16 * rpg;
+    const int tps = (g->n + tr - 1) / tr;
     const long total = (long)(rows / g->n) * tps;
     const float* AIhub = nullptr;
     if (int e = gn_hub_gather(g, rows / g->n, 64, ZI, nullptr, &AIhub, nullptr, st)) return e;
-    const int k = wgs_per_cu();
+    const int k = wgs_per_cu() > 0 ? (rpg == 1 ? wgs_per_cu() * 3 / 2 : wgs_per_cu()) : 0;
     // (measured: shrinking the grid so that every persistent workgroup gets the same number of tiles is 3 % SLOWER
     //  than filling all 4 x CUs slots and accepting a +-1 tile imbalance -- residency matters more)
     const int grid = (int)(k > 0 ? std::min<long>(total, (long)num_cus() * k) : total);
     const bool prj = PR != nullptr;
-#define GN_STEP(F, P)                                                                                                    \
-    hipLaunchKernelGGL((k_step64<F, P>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, \
-                       ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,        \
+#define GN_STEP(F, P, Q)                                                                                                    \
+    hipLaunchKernelGGL((k_step64<F, P, Q>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, \
+                       ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,           \
                        p->linearS2_bias, PR, out, g->hubidx, AIhub, g->n_hub)
-    if (fuse) { if (prj) GN_STEP(true, true); else GN_STEP(true, false); }
-    else { if (prj) GN_STEP(false, true); else GN_STEP(false, false); }
+#define GN_STEP_Q(F, P) do { if (rpg == 1) GN_STEP(F, P, 1); else GN_STEP(F, P, 2); } while (0)
+    if (fuse) { if (prj) GN_STEP_Q(true, true); else GN_STEP_Q(true, false); }
+    else { if (prj) GN_STEP_Q(false, true); else GN_STEP_Q(false, false); }
+#undef GN_STEP_Q
 #undef GN_STEP
     GN_LAUNCH_CHECK();
     return 0;

@@ -8,10 +8,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TS 68            // LDS row stride in floats (272 B): 16-B aligned rows, spreads banks
 #define TILE_ROWS 32
 
-__device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each).  __frcp_rn would expand to the IEEE-exact division sequence (~10 VALU
+// instructions per value, 16 values per wave and tile) for nothing: the result is within 2e-7 either way.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// uniform base pointer + 32-bit BYTE offset: the compiler emits `global_load/store v, v_off, s[base:base+1]`, one
+// 32-bit VALU op per address instead of a 64-bit shift-add pair (the step kernel is VALU-issue sensitive)
+__device__ __forceinline__ float4 ld4o(const float* b, unsigned off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(b) + off);
+}
+__device__ __forceinline__ void st4o(float* b, unsigned off, float4 v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(b) + off) = v;
+}
 // streaming (read-once / write-once) accesses: keep them out of the way of the gather table in L2
 typedef float v4f __attribute__((ext_vector_type(4)));
 template <bool NT>
@@ -75,6 +85,31 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ Tin, const f
         Tout[(4 * kq + r) * TS + 16 * w + i] = SIGMOID ? sigmoid_f(acc0[r]) : acc0[r];
         Tout[(16 + 4 * kq + r) * TS + 16 * w + i] = SIGMOID ? sigmoid_f(acc1[r]) : acc1[r];
     }
+}
+
+// 16-row variant: out[16][64] = sigmoid(X[16][64] W^T + b).  One 16x16 output tile per wave; K = 64 is split over
+// two accumulators (k-steps of even / odd m) so the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 is hidden.
+__device__ __forceinline__ void mfma_tile16(const float* __restrict__ Tin, const float* __restrict__ Wl,
+                                            float* __restrict__ Tout, float bias_l, int w, int lane) {
+    const int i = lane & 15, kq = lane >> 4;
+    f32x4 acc0 = {bias_l, bias_l, bias_l, bias_l}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; m += 2) {
+        const float4 b0 = *reinterpret_cast<const float4*>(Wl + (16 * w + i) * TS + 16 * kq + 4 * m);
+        const float4 b1 = *reinterpret_cast<const float4*>(Wl + (16 * w + i) * TS + 16 * kq + 4 * m + 4);
+        const float4 a0 = *reinterpret_cast<const float4*>(Tin + i * TS + 16 * kq + 4 * m);
+        const float4 a1 = *reinterpret_cast<const float4*>(Tin + i * TS + 16 * kq + 4 * m + 4);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Tout[(4 * kq + r) * TS + 16 * w + i] = sigmoid_f(acc0[r] + acc1[r]);
 }
 
 // Wl[r][c] = W[r][c] (forward: out = X W^T), or TRANSPOSE: Wl[c][r] = W[r][c] (backward: out = X W)

@@ -87,8 +87,8 @@ extern "C" int gnode_profile_read(double* gather_ms, int64_t* gather_launches, d
 
 // --------------------------------------------------------------------------- device helpers
 __device__ __forceinline__ float gn_sigmoid(float x) {
-    // 1 / (1 + exp(-x)) with the hardware exp2/rcp (<= 2 ulp each)
-    return __frcp_rn(1.0f + __expf(-x));
+    // 1 / (1 + exp(-x)) with the hardware exp2/rcp (v_exp_f32, v_rcp_f32: 1 ulp each)
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -126,7 +126,7 @@ __device__ __forceinline__ void readout_row(float4 yS, float4 yI, float4 yR, boo
     }
     float m = fmaxf(qS, fmaxf(qI, qR));
     float eS = __expf(qS - m), eI = __expf(qI - m), eR = __expf(qR - m);
-    float inv = 1.0f / (eS + eI + eR);
+    float inv = __builtin_amdgcn_rcpf(eS + eI + eR);
     pS = eS * inv; pI = eI * inv; pR = eR * inv;
 }
 
