@@ -18,11 +18,9 @@
 // partial buffer [NWG][NP] that it updates with plain read-modify-writes across all
 // launches (fixed grid, fixed row->workgroup map); one final kernel sums the slots in
 // order.  No float atomics, bitwise reproducible run to run.
-#include "gnode_common.h"
+#include "gnode_bwd.h"
 #include "gnode_mfma64.h"
 #include <algorithm>
-
-#define BWD_NWG 768     // 3 workgroups per CU (52 KB of LDS each) on 256 CUs
 
 __device__ __forceinline__ float4 ld4b(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4b(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -35,20 +33,6 @@ __device__ __forceinline__ float gsum(float v) {
     for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, LPR);
     return v;
 }
-
-// partial-buffer layout per workgroup (floats)
-struct PartLayout {
-    int H;
-    __host__ __device__ int oW() const { return 0; }
-    __host__ __device__ int ob() const { return H * H; }
-    __host__ __device__ int ow3() const { return H * H + H; }
-    __host__ __device__ int ob3() const { return H * H + 5 * H; }
-    __host__ __device__ int ow2() const { return H * H + 5 * H + 4; }
-    __host__ __device__ int ob2() const { return H * H + 5 * H + 8; }
-    __host__ __device__ int ow1() const { return H * H + 5 * H + 9; }
-    __host__ __device__ int ob1() const { return H * H + 6 * H + 9; }
-    __host__ __device__ int total() const { return H * H + 7 * H + 9; }
-};
 
 // Deterministic in-workgroup reduction of per-group contributions staged in LDS:
 // red[group][NE] -> part[e] += sum_groups (fixed order).
@@ -488,13 +472,16 @@ __global__ __launch_bounds__(256) void k_enc_bwd(const float* __restrict__ a, co
     flush_groups(red, G, 2 * H, part_all + (size_t)blockIdx.x * L.total() + L.ow1());
 }
 
-__global__ __launch_bounds__(256) void k_reduce_parts(const float* __restrict__ part_all, int nwg, int total,
-                                                      float* __restrict__ out) {
+// Sum the workgroup slots in order and write each parameter's gradient straight to its destination.
+struct GradDst { float* dst[8]; int off[9]; };
+__global__ __launch_bounds__(256) void k_reduce_parts(const float* __restrict__ part_all, int nwg, int total, GradDst gd) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     float s = 0.f;
     for (int w = 0; w < nwg; ++w) s += part_all[(size_t)w * total + e];
-    out[e] = s;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (e >= gd.off[k] && e < gd.off[k + 1]) gd.dst[k][e - gd.off[k]] = s;
 }
 
 // --------------------------------------------------------------------------- host
@@ -566,6 +553,13 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     float* gamma = (float*)(ws + 8 * slab_b + vec_b);
     float* part = (float*)(ws + 8 * slab_b + 2 * vec_b);
     float* red = (float*)(ws + 8 * slab_b + 2 * vec_b + gn_align((size_t)BWD_NWG * L.total() * sizeof(float)));
+    int slots_used = 1;                                  // highest workgroup slot any launch wrote, for the final reduction
+    const bool tiny = gn_tiny_bwd64_ok(g, rows, H, n_steps);
+    if (tiny) {
+        // graphs that fit one workgroup: the whole sweep is one launch writing slot b for sample b (gnode_bwd_tiny.hip)
+        if (int e = gn_launch_tiny_bwd64(g, rows, x, p, dt_host, n_steps, out_rows_host, n_out, sol, gS, gI, gR, part, st)) return e;
+        slots_used = (int)(rows / g->n);
+    } else {
     GN_HIP(hipMemsetAsync(a, 0, 3 * slab * sizeof(float), st));
     GN_HIP(hipMemsetAsync(part, 0, (size_t)BWD_NWG * L.total() * sizeof(float), st));
     hipLaunchKernelGGL(k_extract_bg, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, sol + 3 * slab, (long)rows, H,
@@ -573,7 +567,6 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     GN_LAUNCH_CHECK();
 
     const int lpr = lpr_of(H), rpw = 256 / lpr;
-    int slots_used = 1;                                  // highest workgroup slot any launch wrote, for the final reduction
     auto slot_of = [&](int gi) -> int {
         if (!out_rows_host) return gi;
         for (int i = 0; i < n_out; ++i) if (out_rows_host[i] == gi) return i;
@@ -641,14 +634,16 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_enc_bwd<LPR>, dim3(egrid), dim3(256), lds, st, a, sol, x, (long)rows, H, part));
         GN_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((L.total() + 255) / 256), dim3(256), 0, st, part, slots_used, L.total(), red);
+    }   // !tiny
+    // slot layout order == PartLayout order: W, b, w3, b3, w2, b2, w1, b1
+    GradDst gd;
+    gd.dst[0] = (float*)grads->odefunc_linear_weight; gd.dst[1] = (float*)grads->odefunc_linear_bias;
+    gd.dst[2] = (float*)grads->linear3_weight;        gd.dst[3] = (float*)grads->linear3_bias;
+    gd.dst[4] = (float*)grads->linearS2_weight;       gd.dst[5] = (float*)grads->linearS2_bias;
+    gd.dst[6] = (float*)grads->linearS1_weight;       gd.dst[7] = (float*)grads->linearS1_bias;
+    const int offs[9] = {L.oW(), L.ob(), L.ow3(), L.ob3(), L.ow2(), L.ob2(), L.ow1(), L.ob1(), L.total()};
+    for (int k = 0; k < 9; ++k) gd.off[k] = offs[k];
+    hipLaunchKernelGGL(k_reduce_parts, dim3((L.total() + 255) / 256), dim3(256), 0, st, part, slots_used, L.total(), gd);
     GN_LAUNCH_CHECK();
-    struct { float* dst; int off; int cnt; } outv[] = {
-        {(float*)grads->odefunc_linear_weight, L.oW(), H * H}, {(float*)grads->odefunc_linear_bias, L.ob(), H},
-        {(float*)grads->linear3_weight, L.ow3(), 4 * H},       {(float*)grads->linear3_bias, L.ob3(), 4},
-        {(float*)grads->linearS2_weight, L.ow2(), 4},          {(float*)grads->linearS2_bias, L.ob2(), 1},
-        {(float*)grads->linearS1_weight, L.ow1(), H},          {(float*)grads->linearS1_bias, L.ob1(), H}};
-    for (auto& o : outv)
-        GN_HIP(hipMemcpyAsync(o.dst, red + o.off, sizeof(float) * o.cnt, hipMemcpyDeviceToDevice, st));
     return 0;
 }

@@ -27,6 +27,12 @@ def _rel(a, b):
     (40, 100, 1, 128, 3, 0.5, False),
     (40, 120, 2, 64, 5, 0.5, False),       # n <= 64: the forward that feeds this backward is the single-launch kernel
     (64, 200, 1, 64, 4, 0.5, True),
+    # n <= 64 at H = 64: the whole adjoint sweep is ONE launch (gnode_bwd_tiny.hip)
+    (34, 78, 1, 64, 20, 0.5, True),        # karate-sized, the reference's shipped configuration (39 intervals)
+    (20, 40, 3, 64, 3, 0.5, False),        # one row tile
+    (62, 159, 5, 64, 5, 0.5, False),       # dolphins-sized, two row tiles
+    (24, 200, 2, 64, 3, 0.5, False),       # dense: rows longer than the 16 neighbour ids cached in registers
+    (33, 60, 2, 64, 1, 0.5, False),        # a single grid point: head + encoder only, no interval
 ])
 def test_param_grads_vs_oracle(n, m, B, H, maxTime, deltaT, sub, dev, skewed=False):
     import torch
