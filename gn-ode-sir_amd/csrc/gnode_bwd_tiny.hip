@@ -154,39 +154,63 @@ __global__ __launch_bounds__(512) void k_tiny_bwd64(const int* __restrict__ rowp
     for (int kt = 0; kt < 4; ++kt) accW[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float accb = 0.f;
 
-    // dL/dsol at grid point gi enters through the head (a += ...), gnode_bwd.hip `head`
-    auto head_at = [&](int gi) {
+    // Rows of sol at one grid point: y_i feeds the interval's MFMAs AND (one interval earlier in the sweep) the head's
+    // VJP at that grid point, so each row is fetched once, one interval ahead of its first use.
+    struct GridRows { float4 y[2][3]; float gout[2][3]; };
+    auto fetch = [&](int gi, GridRows& r) {
         const int s = sched.slot[gi];
-        if (s < 0) return;
         const float* Yg = sol + (size_t)gi * 4 * slab;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            float4 y[3] = {zero4(), zero4(), zero4()};
-            float gout[3] = {0.f, 0.f, 0.f};
-            if (valid[p]) {
-                y[0] = ld4g(Yg + off[p]); y[1] = ld4g(Yg + slab + off[p]); y[2] = ld4g(Yg + 2 * slab + off[p]);
+            r.y[p][0] = r.y[p][1] = r.y[p][2] = zero4();
+            r.gout[p][0] = r.gout[p][1] = r.gout[p][2] = 0.f;
+            if (!valid[p]) continue;
+            r.y[p][0] = ld4g(Yg + off[p]); r.y[p][1] = ld4g(Yg + slab + off[p]);
+            if (s >= 0) {
+                r.y[p][2] = ld4g(Yg + 2 * slab + off[p]);
                 const size_t o = (size_t)s * rows + base + node[p];
-                gout[0] = gS[o]; gout[1] = gI[o]; gout[2] = gR[o];
+                r.gout[p][0] = gS[o]; r.gout[p][1] = gI[o]; r.gout[p][2] = gR[o];
             }
-            head_vjp64(y, gout, w3v, b3, w2, b2, aS[p], aI[p], aR[p], hacc);     // invalid rows: gout = 0 -> adds nothing
         }
     };
+    // dL/dsol at grid point gi enters through the head (a += ...), gnode_bwd.hip `head`
+    auto head_at = [&](int gi, const GridRows& r) {
+        if (sched.slot[gi] < 0) return;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)       // padding rows: gout = 0 -> adds nothing
+            head_vjp64(r.y[p], r.gout[p], w3v, b3, w2, b2, aS[p], aI[p], aR[p], hacc);
+    };
 
-    head_at(sched.n_steps);
+    // a tile whose rows 16..31 are all padding (karate: n = 34 -> tile 1 holds 2 rows) runs half the MFMAs, and the
+    // gW contraction only visits the 4-row slices that hold real rows (padding rows of dpre are zero)
+    const int rows_here = min(TILE_ROWS, n - t * TILE_ROWS);
+    const bool blk2 = rows_here > 16;
+    const int s8_end = (rows_here + 3) / 4;
+    // rows 16..31 of the tile buffers are read by the row owners even when no MFMA writes them
+    if (!blk2)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (lr[p] >= 16) {
+                *reinterpret_cast<float4*>(Dt0 + lr[p] * TS + 4 * sub) = zero4();
+                *reinterpret_cast<float4*>(ZIm + lr[p] * TS + 4 * sub) = zero4();
+            }
+    GridRows cur, nxt;
+    fetch(sched.n_steps, cur);
+    head_at(sched.n_steps, cur);
     __syncthreads();                                                            // W, W^T staged
     for (int i = sched.n_steps; i >= 1; --i) {
         const float dt = sched.dt[i - 1];
-        const float* Yi = sol + (size_t)i * 4 * slab;
-        // 1. y_i rows of this tile
+        // 1. y_i rows of this tile (fetched one interval ago); start fetching grid point i-1
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            *reinterpret_cast<float4*>(Yt0 + lr[p] * TS + 4 * sub) = valid[p] ? ld4g(Yi + off[p]) : zero4();
-            *reinterpret_cast<float4*>(Yt1 + lr[p] * TS + 4 * sub) = valid[p] ? ld4g(Yi + slab + off[p]) : zero4();
+            *reinterpret_cast<float4*>(Yt0 + lr[p] * TS + 4 * sub) = cur.y[p][0];
+            *reinterpret_cast<float4*>(Yt1 + lr[p] * TS + 4 * sub) = cur.y[p][1];
         }
+        fetch(i - 1, nxt);
         __syncthreads();
         // 2. Z_S (into Dt0 for now) and Z_I (straight into the gather table)
-        mfma_tile<true>(Yt0, Wl, Dt0, bias_l, w, lane);
-        mfma_tile<true>(Yt1, Wl, ZIm, bias_l, w, lane);
+        if (blk2) { mfma_tile<true>(Yt0, Wl, Dt0, bias_l, w, lane); mfma_tile<true>(Yt1, Wl, ZIm, bias_l, w, lane); }
+        else { mfma_tile16<true>(Yt0, Wl, Dt0, bias_l, w, lane); mfma_tile16<true>(Yt1, Wl, ZIm, bias_l, w, lane); }
         __syncthreads();
         // 3. q = beta (a_I - a_S) Z_S
         float4 zs[2], zi[2];
@@ -226,6 +250,7 @@ __global__ __launch_bounds__(512) void k_tiny_bwd64(const int* __restrict__ rowp
             const float* Y = X ? Yt1 : Yt0;
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) {
+                if (s8 >= s8_end) break;
                 const int rr = 4 * s8 + kq;
                 const float av = D[rr * TS + 16 * w + i16];
 #pragma unroll
@@ -240,8 +265,8 @@ __global__ __launch_bounds__(512) void k_tiny_bwd64(const int* __restrict__ rowp
         }
         __syncthreads();
         // 5b. g_Y = dpre W over the y tiles, a += g_Y
-        mfma_tile<false>(Dt0, WlT, Yt0, 0.f, w, lane);
-        mfma_tile<false>(Dt1, WlT, Yt1, 0.f, w, lane);
+        if (blk2) { mfma_tile<false>(Dt0, WlT, Yt0, 0.f, w, lane); mfma_tile<false>(Dt1, WlT, Yt1, 0.f, w, lane); }
+        else { mfma_tile16<false>(Dt0, WlT, Yt0, 0.f, w, lane); mfma_tile16<false>(Dt1, WlT, Yt1, 0.f, w, lane); }
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -252,7 +277,8 @@ __global__ __launch_bounds__(512) void k_tiny_bwd64(const int* __restrict__ rowp
             aI[p].x += uI.x; aI[p].y += uI.y; aI[p].z += uI.z; aI[p].w += uI.w;
         }
         // 6. dL/dsol[i-1]
-        head_at(i - 1);
+        head_at(i - 1, nxt);
+        cur = nxt;
     }
 
     // encoder backward at grid point 0: y0_X = relu(s_X w1 + b1) (ode_nn_ngraph_sim.py:151-156)

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, (RPG == 2 ? 4 : 6)) void k_step64(const int* _
         }
         __syncthreads();
         // -------- P2: Z_S on the matrix cores
-        if (RPG == 2) mfma_tile<true>(T, Wl, T2, bias_l, w, lane); else mfma_tile16(T, Wl, T2, bias_l, w, lane);
+        if (RPG == 2) mfma_tile<true>(T, Wl, T2, bias_l, w, lane); else mfma_tile16<true>(T, Wl, T2, bias_l, w, lane);
         __syncthreads();
         // -------- P3: SIR derivative (ode_nn_ngraph_sim.py:75-77), Euler update, read-out
 #pragma unroll
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, (RPG == 2 ? 4 : 6)) void k_step64(const int* _
         if (FUSE) {
             // -------- P4: Z_I of the next step from the updated Y_I rows
             __syncthreads();
-            if (RPG == 2) mfma_tile<true>(T, Wl, T2, bias_l, w, lane); else mfma_tile16(T, Wl, T2, bias_l, w, lane);
+            if (RPG == 2) mfma_tile<true>(T, Wl, T2, bias_l, w, lane); else mfma_tile16<true>(T, Wl, T2, bias_l, w, lane);
             __syncthreads();
 #pragma unroll
             for (int p = 0; p < RPG; ++p)
@@ -346,6 +346,12 @@ __global__ __launch_bounds__(768) void k_tiny64(const int* __restrict__ rowptr, 
         }
     __syncthreads();
     float* Zc = ZA; float* Zn = ZB;
+    // a tile whose rows 16..31 are all padding (karate: n = 34 -> tile 1 holds 2 rows) runs half the MFMAs
+    const bool blk2 = n - t * TILE_ROWS > 16;
+    if (!blk2)                                     // rows 16..31 of the scratch tile are read (by padding rows) but never written
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (lrow[p] - t * TILE_ROWS >= 16) *reinterpret_cast<float4*>(T2 + (lrow[p] - t * TILE_ROWS) * TS + 4 * sub) = zero4();
     for (int k = 0; k < sched.n_steps; ++k) {
         const float dt = sched.dt[k];
         const int slot = sched.slot[k];
@@ -353,7 +359,8 @@ __global__ __launch_bounds__(768) void k_tiny64(const int* __restrict__ rowptr, 
         float4 ai[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) ai[p] = gather_row_lds(col, Zc, e_lo[p], e_hi[p], first16[p], sub);
-        mfma_tile<true>(YS + t * tile_f, Wl, T2, bias_l, w, lane);
+        if (blk2) mfma_tile<true>(YS + t * tile_f, Wl, T2, bias_l, w, lane);
+        else mfma_tile16<true>(YS + t * tile_f, Wl, T2, bias_l, w, lane);
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -401,7 +408,8 @@ __global__ __launch_bounds__(768) void k_tiny64(const int* __restrict__ rowptr, 
             }
         }
         __syncthreads();                           // Y_I tile complete, T2 free
-        mfma_tile<true>(YI + t * tile_f, Wl, T2, bias_l, w, lane);   // Z_I of the next step
+        if (blk2) mfma_tile<true>(YI + t * tile_f, Wl, T2, bias_l, w, lane);   // Z_I of the next step
+        else mfma_tile16<true>(YI + t * tile_f, Wl, T2, bias_l, w, lane);
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < 2; ++p)

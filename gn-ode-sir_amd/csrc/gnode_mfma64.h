@@ -89,6 +89,7 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ Tin, const f
 
 // 16-row variant: out[16][64] = sigmoid(X[16][64] W^T + b).  One 16x16 output tile per wave; K = 64 is split over
 // two accumulators (k-steps of even / odd m) so the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 is hidden.
+template <bool SIGMOID = true>
 __device__ __forceinline__ void mfma_tile16(const float* __restrict__ Tin, const float* __restrict__ Wl,
                                             float* __restrict__ Tout, float bias_l, int w, int lane) {
     const int i = lane & 15, kq = lane >> 4;
@@ -109,7 +110,7 @@ __device__ __forceinline__ void mfma_tile16(const float* __restrict__ Tin, const
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Tout[(4 * kq + r) * TS + 16 * w + i] = sigmoid_f(acc0[r] + acc1[r]);
+    for (int r = 0; r < 4; ++r) Tout[(4 * kq + r) * TS + 16 * w + i] = SIGMOID ? sigmoid_f(acc0[r] + acc1[r]) : acc0[r] + acc1[r];
 }
 
 // Wl[r][c] = W[r][c] (forward: out = X W^T), or TRANSPOSE: Wl[c][r] = W[r][c] (backward: out = X W)
