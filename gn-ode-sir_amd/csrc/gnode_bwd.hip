@@ -20,7 +20,9 @@
 // order.  No float atomics, bitwise reproducible run to run.
 #include "gnode_bwd.h"
 #include "gnode_mfma64.h"
+#include "gnode_head64.h"
 #include <algorithm>
+#include <cstdlib>
 
 __device__ __forceinline__ float4 ld4b(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4b(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -441,6 +443,185 @@ __global__ __launch_bounds__(256) void k_bwd_step64(const int* __restrict__ rowp
     if (threadIdx.x < 64) part[L.ob() + threadIdx.x] += dt * accb;
 }
 
+// --------------------------------------------------------------------------- ONE launch per backward interval (H = 64)
+// k_bwd_step64's work for interval i, then -- every piece of it row-local -- what used to be two more launches:
+//   * the head's VJP at grid point i-1 (dL/dsol[i-1] enters a while the rows are still in registers), and
+//   * Z(y_{i-1}) and q = beta (a_I - a_S) Z_S for the NEXT interval, written to the other half of the double-buffered
+//     gather tables (the forward's P4 trick), so no separate node-MLP launch exists in the sweep.
+// One copy of W in LDS serves both contractions (X W^T for Z, X W for g_Y): 52 KB, 3 workgroups per CU.
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+                                                     long rows, int tiles_per_sample, long total_tiles,
+                                                     float* __restrict__ ZS, const float* __restrict__ ZIc,
+                                                     const float* __restrict__ Qc, float* __restrict__ ZIn,
+                                                     float* __restrict__ Qn, const float* __restrict__ Ysol,
+                                                     const float* __restrict__ Yprev, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, const float* __restrict__ beta,
+                                                     const float* __restrict__ gamma, float dt, float* __restrict__ a,
+                                                     float* __restrict__ part_all, const float* __restrict__ gS,
+                                                     const float* __restrict__ gI, const float* __restrict__ gR,
+                                                     const float* __restrict__ w3, const float* __restrict__ b3,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     const int* __restrict__ hubidx, const float* __restrict__ AIhub,
+                                                     const float* __restrict__ GQhub, int n_hub, int do_next) {
+    __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
+    __shared__ __attribute__((aligned(16))) float Dt[2][TILE_ROWS * TS];
+    __shared__ __attribute__((aligned(16))) float Yt[2][TILE_ROWS * TS];
+    const PartLayout L{64};
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
+    const int i = lane & 15, kq = lane >> 4;
+    load_W_to_lds<false>(W, Wl);
+    const float bias_l = bias[16 * w + i];
+    const size_t slab = (size_t)rows * 64;
+    const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
+    const bool head = gS != nullptr;
+    HeadAcc hacc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hacc.dw3[k] = zero4(); hacc.db3[k] = 0.f; hacc.dw2[k] = 0.f; }
+    hacc.db2 = 0.f;
+    f32x4 accW[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) accW[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
+    for (long t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const long b = t / tiles_per_sample;
+        const int tile = (int)(t - b * tiles_per_sample);
+        const long base = b * n;
+        bool valid[2]; size_t off[2]; float4 aS[2], aI[2], aR[2]; float bt[2];
+        __syncthreads();                                   // previous tile fully consumed (and W staged)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int node = tile * TILE_ROWS + lr[p];
+            valid[p] = node < n;
+            off[p] = (size_t)(base + node) * 64 + 4 * sub;
+            float4 ai, gq;
+            const int hub = (hubidx && valid[p]) ? hubidx[node] : -1;
+            if (hub >= 0) {
+                ai = ld4g(AIhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+                gq = ld4g(GQhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+            } else {
+                gather2_row64(rowptr, col, ZIc + (size_t)base * 64, Qc + (size_t)base * 64, node, valid[p], sub, ai, gq);
+            }
+            float4 dS = zero4(), dI = zero4();
+            aS[p] = zero4(); aI[p] = zero4(); aR[p] = zero4(); bt[p] = 0.f;
+            if (valid[p]) {
+                bt[p] = beta[base + node];
+                const float gm = gamma[base + node];
+                aS[p] = ld4g(a + off[p]); aI[p] = ld4g(a + slab + off[p]); aR[p] = ld4g(a + 2 * slab + off[p]);
+                const float4 zs = ld4g(ZS + off[p]), zi = ld4g(ZIc + off[p]);
+#define GN_DP(c)                                                               \
+                {                                                              \
+                    const float v = bt[p] * (aI[p].c - aS[p].c);               \
+                    dS.c = (v * ai.c) * (zs.c * (1.0f - zs.c));                \
+                    dI.c = (gq.c + gm * (aR[p].c - aI[p].c)) * (zi.c * (1.0f - zi.c)); \
+                }
+                GN_DP(x) GN_DP(y) GN_DP(z) GN_DP(w)
+#undef GN_DP
+            }
+            *reinterpret_cast<float4*>(&Dt[0][lr[p] * TS + 4 * sub]) = dS;
+            *reinterpret_cast<float4*>(&Dt[1][lr[p] * TS + 4 * sub]) = dI;
+            *reinterpret_cast<float4*>(&Yt[0][lr[p] * TS + 4 * sub]) = valid[p] ? ld4g(Ysol + off[p]) : zero4();
+            *reinterpret_cast<float4*>(&Yt[1][lr[p] * TS + 4 * sub]) = valid[p] ? ld4g(Ysol + slab + off[p]) : zero4();
+        }
+        __syncthreads();
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const int rr = 4 * s8 + kq;
+                const float av = Dt[X][rr * TS + 16 * w + i];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    accW[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Yt[X][rr * TS + 16 * kt + i], accW[kt], 0, 0, 0);
+            }
+        }
+        if (threadIdx.x < 64) {
+            float sacc = 0.f;
+            for (int rr = 0; rr < TILE_ROWS; ++rr) sacc += Dt[0][rr * TS + threadIdx.x] + Dt[1][rr * TS + threadIdx.x];
+            accb += sacc;
+        }
+        __syncthreads();
+        mfma_tile<false, true>(Dt[0], Wl, Yt[0], 0.f, w, lane);       // g_Y = dpre W
+        mfma_tile<false, true>(Dt[1], Wl, Yt[1], 0.f, w, lane);
+        __syncthreads();
+        // a += dt g_Y; then, row by row: fetch y_{i-1}, park its S/I rows in the (now free) own rows of Yt for the next
+        // tables, and take dL/dsol[i-1] through the head.  Padding rows carry y = 0, gout = 0 and add nothing (the
+        // head's row sums are group-wide, so lanes stay converged).
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float4 y[3] = {zero4(), zero4(), zero4()};
+            float gout[3] = {0.f, 0.f, 0.f};
+            if (valid[p]) {
+                const float4 uS = *reinterpret_cast<const float4*>(&Yt[0][lr[p] * TS + 4 * sub]);
+                const float4 uI = *reinterpret_cast<const float4*>(&Yt[1][lr[p] * TS + 4 * sub]);
+                aS[p].x += dt * uS.x; aS[p].y += dt * uS.y; aS[p].z += dt * uS.z; aS[p].w += dt * uS.w;
+                aI[p].x += dt * uI.x; aI[p].y += dt * uI.y; aI[p].z += dt * uI.z; aI[p].w += dt * uI.w;
+                if (head || do_next) { y[0] = ld4g(Yprev + off[p]); y[1] = ld4g(Yprev + slab + off[p]); }
+                if (head) {
+                    y[2] = ld4g(Yprev + 2 * slab + off[p]);
+                    const size_t o = (size_t)(base + tile * TILE_ROWS + lr[p]);
+                    gout[0] = gS[o]; gout[1] = gI[o]; gout[2] = gR[o];
+                }
+            }
+            if (do_next) {
+                *reinterpret_cast<float4*>(&Yt[0][lr[p] * TS + 4 * sub]) = y[0];
+                *reinterpret_cast<float4*>(&Yt[1][lr[p] * TS + 4 * sub]) = y[1];
+            }
+            if (head) {
+                float4 w3v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w3v[k] = ld4g(w3 + k * 64 + 4 * sub);      // L1-resident
+                head_vjp64(y, gout, w3v, b3, w2, b2, aS[p], aI[p], aR[p], hacc);
+                if (valid[p]) st4g(a + 2 * slab + off[p], aR[p]);
+            }
+            if (valid[p]) { st4g(a + off[p], aS[p]); st4g(a + slab + off[p], aI[p]); }
+        }
+        if (do_next) {
+            // Z(y_{i-1}) and q for the next interval
+            __syncthreads();
+            mfma_tile<true>(Yt[0], Wl, Dt[0], bias_l, w, lane);
+            mfma_tile<true>(Yt[1], Wl, Dt[1], bias_l, w, lane);
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (!valid[p]) continue;
+                const float4 zs = *reinterpret_cast<const float4*>(&Dt[0][lr[p] * TS + 4 * sub]);
+                const float4 zi = *reinterpret_cast<const float4*>(&Dt[1][lr[p] * TS + 4 * sub]);
+                st4g(ZS + off[p], zs); st4g(ZIn + off[p], zi);
+                st4g(Qn + off[p], make_float4(bt[p] * (aI[p].x - aS[p].x) * zs.x, bt[p] * (aI[p].y - aS[p].y) * zs.y,
+                                              bt[p] * (aI[p].z - aS[p].z) * zs.z, bt[p] * (aI[p].w - aS[p].w) * zs.w));
+            }
+        }
+    }
+    float* part = part_all + (size_t)blockIdx.x * L.total();
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            part[L.oW() + (16 * w + 4 * kq + reg) * 64 + 16 * kt + i] += dt * accW[kt][reg];
+    if (threadIdx.x < 64) part[L.ob() + threadIdx.x] += dt * accb;
+    if (head) {
+        // lane-group partials of the head's parameter gradients -> this workgroup's slot, fixed order
+        __syncthreads();
+        constexpr int NE = 4 * 64 + 12;               // 4*64 + 9 used, rows kept 16-B aligned
+        float* red = &Dt[0][0];                       // 16 groups x 268 floats = 17 KB <= the two Dt tiles
+        float* mine = red + (size_t)(threadIdx.x >> 4) * NE;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(mine + k * 64 + 4 * sub) = hacc.dw3[k];
+        if (sub == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mine[256 + k] = hacc.db3[k]; mine[260 + k] = hacc.dw2[k]; }
+            mine[264] = hacc.db2;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 265; e += 256) {
+            float s = 0.f;
+            for (int gi = 0; gi < 16; ++gi) s += red[(size_t)gi * NE + e];
+            part[L.ow3() + e] += s;
+        }
+    }
+}
+
 // --------------------------------------------------------------------------- encoder backward
 template <int LPR>
 __global__ __launch_bounds__(256) void k_enc_bwd(const float* __restrict__ a, const float* __restrict__ sol0,
@@ -586,6 +767,38 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     };
     if (int e = head(G - 1)) return e;
     const size_t mlp_lds = ((size_t)H * H + (size_t)4 * rpw * H) * sizeof(float);
+    static const bool fuse64 = [] { const char* e = getenv("GNODE_BWD_FUSE"); return !(e && e[0] == '0'); }();
+    if (H == 64 && fuse64 && n_steps >= 1) {
+        // one launch per interval: a[3] | Z_S | Z_I(0) | q(0) | Z_I(1) | q(1)  (Z_S is row-local, the gather tables ping-pong)
+        float* ZS = Z; float* ZIb[2] = {Z + slab_b / sizeof(float), dpre};
+        float* Qb[2] = {q, dpre + slab_b / sizeof(float)};
+        const long mt = (2 * rows + TILE_ROWS - 1) / TILE_ROWS;
+        hipLaunchKernelGGL(k_mlp64_q, dim3((unsigned)std::min<long>(mt, 1024)), dim3(256), 0, st, sol + (size_t)(G - 1) * 4 * slab,
+                           p->odefunc_linear_weight, p->odefunc_linear_bias, Z, a, beta, q, (long)rows);
+        GN_LAUNCH_CHECK();
+        const int tps = (g->n + TILE_ROWS - 1) / TILE_ROWS;
+        const long total = (long)(rows / g->n) * tps;
+        // 3 workgroups per CU (the LDS limit) cost 17 spilled dwords per lane, 2 run spill-free: measured on the 75k
+        // graph, 4 samples, 481 vs 548 us per interval (unfused three-launch form: 563) -> 3
+        static const int occ = [] { const char* e = getenv("GNODE_BWD_OCC"); return (e && e[0] == '2') ? 2 : 3; }();
+        auto fused_kernel = occ == 3 ? k_bwd_fused64<3> : k_bwd_fused64<2>;
+        const int grid = (int)std::min<long>(occ * 256, total);
+        slots_used = std::max(slots_used, grid);
+        for (int i = G - 1; i >= 1; --i) {
+            const int cur = (G - 1 - i) & 1;
+            const float *AIhub = nullptr, *GQhub = nullptr;
+            if (int e = gn_hub_gather(g, rows / g->n, 64, ZIb[cur], Qb[cur], &AIhub, &GQhub, st)) return e;
+            const int s = slot_of(i - 1);
+            const float* gSs = s >= 0 ? gS + (size_t)s * rows : nullptr;
+            hipLaunchKernelGGL(fused_kernel, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, tps, total, ZS,
+                               ZIb[cur], Qb[cur], ZIb[cur ^ 1], Qb[cur ^ 1], sol + (size_t)i * 4 * slab,
+                               sol + (size_t)(i - 1) * 4 * slab, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma,
+                               dt_host[i - 1], a, part, gSs, s >= 0 ? gI + (size_t)s * rows : nullptr,
+                               s >= 0 ? gR + (size_t)s * rows : nullptr, p->linear3_weight, p->linear3_bias,
+                               p->linearS2_weight, p->linearS2_bias, g->hubidx, AIhub, GQhub, g->n_hub, i > 1 ? 1 : 0);
+            GN_LAUNCH_CHECK();
+        }
+    } else
     for (int i = G - 1; i >= 1; --i) {
         const float* yi = sol + (size_t)i * 4 * slab;
         const float dt = dt_host[i - 1];

@@ -61,14 +61,22 @@ __device__ __forceinline__ int row_bcast(int v) { return dpp_i<0x150 + J>(v); }
 // Wave w owns output features [16w, 16w+16).  v_mfma_f32_16x16x4_f32 operand maps:
 //   A[i][k'] / B[k'][j]: i = j = lane & 15, k' = lane >> 4;  D: col = lane & 15, row = 4*(lane>>4) + reg.
 // k is visited as kappa = 16*(lane>>4) + 4m + c so every fragment fetch is one ds_read_b128.
-template <bool SIGMOID = true>
+// WT: contract with W instead of W^T (out = X W, the backward's g_Y = dpre W) from the SAME staged copy Wl[j][k]:
+// the B fragment is then four ds_read_b32 a row apart instead of one ds_read_b128 -- LDS is far from the bound.
+template <bool SIGMOID = true, bool WT = false>
 __device__ __forceinline__ void mfma_tile(const float* __restrict__ Tin, const float* __restrict__ Wl,
                                           float* __restrict__ Tout, float bias_l, int w, int lane) {
     const int i = lane & 15, kq = lane >> 4;
     f32x4 acc0 = {bias_l, bias_l, bias_l, bias_l}, acc1 = acc0;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        const float4 b = *reinterpret_cast<const float4*>(Wl + (16 * w + i) * TS + 16 * kq + 4 * m);
+        float4 b;
+        if (WT) {
+            const float* bp = Wl + (16 * kq + 4 * m) * TS + 16 * w + i;
+            b = make_float4(bp[0], bp[TS], bp[2 * TS], bp[3 * TS]);
+        } else {
+            b = *reinterpret_cast<const float4*>(Wl + (16 * w + i) * TS + 16 * kq + 4 * m);
+        }
         const float4 a0 = *reinterpret_cast<const float4*>(Tin + i * TS + 16 * kq + 4 * m);
         const float4 a1 = *reinterpret_cast<const float4*>(Tin + (16 + i) * TS + 16 * kq + 4 * m);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);
