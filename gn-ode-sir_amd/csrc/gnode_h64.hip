@@ -128,10 +128,15 @@ __device__ __forceinline__ void readout64(float4 yS, float4 yI, float4 yR, const
     pS = eS * inv; pI = eI * inv; pR = eR * inv;
 }
 
-// RPG = rows per 16-lane group and tile: 2 -> 32-row tiles, 4 workgroups per CU; 1 -> 16-row tiles, half the LDS
-// and far fewer live registers per wave, 6 workgroups per CU.
+#ifndef GN_RPG1_OCC
+#define GN_RPG1_OCC 5
+#endif
+// RPG = rows per 16-lane group and tile: 2 -> 32-row tiles, 4 workgroups per CU; 1 (default) -> 16-row tiles: half
+// the LDS, the two row gathers of a lane group no longer run back to back, and no spills at 5 workgroups per CU.
+// Measured per launch, 75k graph x 8 samples: RPG=2 406 us; RPG=1 at 3/4/5/6/8 workgroups per CU 457/403/380/389/417 us;
+// one sample (latency-bound): 67 -> 59 us, fb-social-size graph (60 tiles): 12.6 -> 8.3 us per step.
 template <bool FUSE, bool PRJ, int RPG>
-__global__ __launch_bounds__(256, (RPG == 2 ? 4 : 6)) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+__global__ __launch_bounds__(256, (RPG == 2 ? 4 : GN_RPG1_OCC)) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                 long rows, int tiles_per_sample, long total_tiles,
                                                 float* Y, const float* __restrict__ ZI,
                                                 float* __restrict__ ZI_next, const float* __restrict__ W,
@@ -513,13 +518,13 @@ int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, flo
                      float* PR, Step64Out out, bool fuse, hipStream_t st) {
     GN_CHECK_ARG(rows < (1L << 24), "H=64 step kernel addresses rows with 32-bit byte offsets: rows=%ld >= 2^24 per launch "
                  "(split the batch)", rows);
-    static const int rpg = [] { const char* e = getenv("GNODE_RPG"); return (e && e[0] == '1') ? 1 : 2; }();
+    static const int rpg = [] { const char* e = getenv("GNODE_RPG"); return (e && e[0] == '2') ? 2 : 1; }();
     const int tr = 16 * rpg;
     const int tps = (g->n + tr - 1) / tr;
     const long total = (long)(rows / g->n) * tps;
     const float* AIhub = nullptr;
     if (int e = gn_hub_gather(g, rows / g->n, 64, ZI, nullptr, &AIhub, nullptr, st)) return e;
-    const int k = wgs_per_cu() > 0 ? (rpg == 1 ? wgs_per_cu() * 3 / 2 : wgs_per_cu()) : 0;
+    const int k = wgs_per_cu() > 0 ? (rpg == 1 ? wgs_per_cu() * GN_RPG1_OCC / 4 : wgs_per_cu()) : 0;
     // (measured: shrinking the grid so that every persistent workgroup gets the same number of tiles is 3 % SLOWER
     //  than filling all 4 x CUs slots and accepting a +-1 tile imbalance -- residency matters more)
     const int grid = (int)(k > 0 ? std::min<long>(total, (long)num_cus() * k) : total);

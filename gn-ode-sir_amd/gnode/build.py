@@ -39,7 +39,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src):
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *os.environ.get("GNODE_EXTRA_FLAGS", "").split(), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
