@@ -449,7 +449,13 @@ __global__ __launch_bounds__(256) void k_bwd_step64(const int* __restrict__ rowp
 //   * Z(y_{i-1}) and q = beta (a_I - a_S) Z_S for the NEXT interval, written to the other half of the double-buffered
 //     gather tables (the forward's P4 trick), so no separate node-MLP launch exists in the sweep.
 // One copy of W in LDS serves both contractions (X W^T for Z, X W for g_Y): 52 KB, 3 workgroups per CU.
-template <int OCC>
+// workgroups per CU of the 16-row-tile form.  Every workgroup owns one slot of the partial-gradient buffer, which has
+// BWD_NWG slots: the grid may never exceed that (a 4-per-CU grid of 1024 would write past the buffer).
+#ifndef GN_BWD_RPG1_OCC
+#define GN_BWD_RPG1_OCC 3
+#endif
+static_assert(GN_BWD_RPG1_OCC * 256 <= BWD_NWG, "fused backward grid exceeds the partial-gradient slots");
+template <int OCC, int RPG>
 __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                      long rows, int tiles_per_sample, long total_tiles,
                                                      float* __restrict__ ZS, const float* __restrict__ ZIc,
@@ -465,15 +471,19 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
                                                      const int* __restrict__ hubidx, const float* __restrict__ AIhub,
                                                      const float* __restrict__ GQhub, int n_hub, int do_next) {
     __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
-    __shared__ __attribute__((aligned(16))) float Dt[2][TILE_ROWS * TS];
-    __shared__ __attribute__((aligned(16))) float Yt[2][TILE_ROWS * TS];
+    constexpr int TR = 16 * RPG;                   // rows per tile (RPG rows per 16-lane group)
+    __shared__ __attribute__((aligned(16))) float tiles[4][TR * TS];
+    float (*Dt)[TR * TS] = &tiles[0];              // Dt[0..1]: dpre_S, dpre_I;  Yt[0..1]: y_S, y_I / g_Y
+    float (*Yt)[TR * TS] = &tiles[2];
     const PartLayout L{64};
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
     const int i = lane & 15, kq = lane >> 4;
     load_W_to_lds<false>(W, Wl);
     const float bias_l = bias[16 * w + i];
     const size_t slab = (size_t)rows * 64;
-    const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
+    int lr[RPG];
+#pragma unroll
+    for (int p = 0; p < RPG; ++p) lr[p] = w * 4 * RPG + 4 * p + g;
     const bool head = gS != nullptr;
     HeadAcc hacc;
 #pragma unroll
@@ -487,11 +497,11 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
         const long b = t / tiles_per_sample;
         const int tile = (int)(t - b * tiles_per_sample);
         const long base = b * n;
-        bool valid[2]; size_t off[2]; float4 aS[2], aI[2], aR[2]; float bt[2];
+        bool valid[RPG]; size_t off[RPG]; float4 aS[RPG], aI[RPG], aR[RPG]; float bt[RPG];
         __syncthreads();                                   // previous tile fully consumed (and W staged)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int node = tile * TILE_ROWS + lr[p];
+        for (int p = 0; p < RPG; ++p) {
+            const int node = tile * TR + lr[p];
             valid[p] = node < n;
             off[p] = (size_t)(base + node) * 64 + 4 * sub;
             float4 ai, gq;
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
 #pragma unroll
         for (int X = 0; X < 2; ++X) {
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) {
+            for (int s8 = 0; s8 < 4 * RPG; ++s8) {
                 const int rr = 4 * s8 + kq;
                 const float av = Dt[X][rr * TS + 16 * w + i];
 #pragma unroll
@@ -537,18 +547,21 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
         }
         if (threadIdx.x < 64) {
             float sacc = 0.f;
-            for (int rr = 0; rr < TILE_ROWS; ++rr) sacc += Dt[0][rr * TS + threadIdx.x] + Dt[1][rr * TS + threadIdx.x];
+            for (int rr = 0; rr < TR; ++rr) sacc += Dt[0][rr * TS + threadIdx.x] + Dt[1][rr * TS + threadIdx.x];
             accb += sacc;
         }
         __syncthreads();
-        mfma_tile<false, true>(Dt[0], Wl, Yt[0], 0.f, w, lane);       // g_Y = dpre W
-        mfma_tile<false, true>(Dt[1], Wl, Yt[1], 0.f, w, lane);
+        if (RPG == 2) {                                                // g_Y = dpre W
+            mfma_tile<false, true>(Dt[0], Wl, Yt[0], 0.f, w, lane); mfma_tile<false, true>(Dt[1], Wl, Yt[1], 0.f, w, lane);
+        } else {
+            mfma_tile16<false, true>(Dt[0], Wl, Yt[0], 0.f, w, lane); mfma_tile16<false, true>(Dt[1], Wl, Yt[1], 0.f, w, lane);
+        }
         __syncthreads();
         // a += dt g_Y; then, row by row: fetch y_{i-1}, park its S/I rows in the (now free) own rows of Yt for the next
         // tables, and take dL/dsol[i-1] through the head.  Padding rows carry y = 0, gout = 0 and add nothing (the
         // head's row sums are group-wide, so lanes stay converged).
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < RPG; ++p) {
             float4 y[3] = {zero4(), zero4(), zero4()};
             float gout[3] = {0.f, 0.f, 0.f};
             if (valid[p]) {
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
                 if (head || do_next) { y[0] = ld4g(Yprev + off[p]); y[1] = ld4g(Yprev + slab + off[p]); }
                 if (head) {
                     y[2] = ld4g(Yprev + 2 * slab + off[p]);
-                    const size_t o = (size_t)(base + tile * TILE_ROWS + lr[p]);
+                    const size_t o = (size_t)(base + tile * TR + lr[p]);
                     gout[0] = gS[o]; gout[1] = gI[o]; gout[2] = gR[o];
                 }
             }
@@ -579,11 +592,11 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
         if (do_next) {
             // Z(y_{i-1}) and q for the next interval
             __syncthreads();
-            mfma_tile<true>(Yt[0], Wl, Dt[0], bias_l, w, lane);
-            mfma_tile<true>(Yt[1], Wl, Dt[1], bias_l, w, lane);
+            if (RPG == 2) { mfma_tile<true>(Yt[0], Wl, Dt[0], bias_l, w, lane); mfma_tile<true>(Yt[1], Wl, Dt[1], bias_l, w, lane); }
+            else { mfma_tile16<true>(Yt[0], Wl, Dt[0], bias_l, w, lane); mfma_tile16<true>(Yt[1], Wl, Dt[1], bias_l, w, lane); }
             __syncthreads();
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < RPG; ++p) {
                 if (!valid[p]) continue;
                 const float4 zs = *reinterpret_cast<const float4*>(&Dt[0][lr[p] * TS + 4 * sub]);
                 const float4 zi = *reinterpret_cast<const float4*>(&Dt[1][lr[p] * TS + 4 * sub]);
@@ -604,7 +617,7 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
         // lane-group partials of the head's parameter gradients -> this workgroup's slot, fixed order
         __syncthreads();
         constexpr int NE = 4 * 64 + 12;               // 4*64 + 9 used, rows kept 16-B aligned
-        float* red = &Dt[0][0];                       // 16 groups x 268 floats = 17 KB <= the two Dt tiles
+        float* red = &tiles[0][0];                    // 16 groups x 268 floats = 17 152 B <= the four 16-row tiles (17 408 B)
         float* mine = red + (size_t)(threadIdx.x >> 4) * NE;
 #pragma unroll
         for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(mine + k * 64 + 4 * sub) = hacc.dw3[k];
@@ -776,13 +789,15 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         hipLaunchKernelGGL(k_mlp64_q, dim3((unsigned)std::min<long>(mt, 1024)), dim3(256), 0, st, sol + (size_t)(G - 1) * 4 * slab,
                            p->odefunc_linear_weight, p->odefunc_linear_bias, Z, a, beta, q, (long)rows);
         GN_LAUNCH_CHECK();
-        const int tps = (g->n + TILE_ROWS - 1) / TILE_ROWS;
-        const long total = (long)(rows / g->n) * tps;
         // 3 workgroups per CU (the LDS limit) cost 17 spilled dwords per lane, 2 run spill-free: measured on the 75k
         // graph, 4 samples, 481 vs 548 us per interval (unfused three-launch form: 563) -> 3
         static const int occ = [] { const char* e = getenv("GNODE_BWD_OCC"); return (e && e[0] == '2') ? 2 : 3; }();
-        auto fused_kernel = occ == 3 ? k_bwd_fused64<3> : k_bwd_fused64<2>;
-        const int grid = (int)std::min<long>(occ * 256, total);
+        static const int rpg = [] { const char* e = getenv("GNODE_BWD_RPG"); return (e && e[0] == '2') ? 2 : 1; }();
+        auto fused_kernel = rpg == 1 ? k_bwd_fused64<GN_BWD_RPG1_OCC, 1> : (occ == 3 ? k_bwd_fused64<3, 2> : k_bwd_fused64<2, 2>);
+        const int tr = 16 * rpg;
+        const int tps = (g->n + tr - 1) / tr;
+        const long total = (long)(rows / g->n) * tps;
+        const int grid = (int)std::min<long>(std::min<long>((rpg == 1 ? GN_BWD_RPG1_OCC : occ) * 256, BWD_NWG), total);
         slots_used = std::max(slots_used, grid);
         for (int i = G - 1; i >= 1; --i) {
             const int cur = (G - 1 - i) & 1;

@@ -97,15 +97,22 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ Tin, const f
 
 // 16-row variant: out[16][64] = sigmoid(X[16][64] W^T + b).  One 16x16 output tile per wave; K = 64 is split over
 // two accumulators (k-steps of even / odd m) so the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 is hidden.
-template <bool SIGMOID = true>
+template <bool SIGMOID = true, bool WT = false>
 __device__ __forceinline__ void mfma_tile16(const float* __restrict__ Tin, const float* __restrict__ Wl,
                                             float* __restrict__ Tout, float bias_l, int w, int lane) {
     const int i = lane & 15, kq = lane >> 4;
     f32x4 acc0 = {bias_l, bias_l, bias_l, bias_l}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 4; m += 2) {
-        const float4 b0 = *reinterpret_cast<const float4*>(Wl + (16 * w + i) * TS + 16 * kq + 4 * m);
-        const float4 b1 = *reinterpret_cast<const float4*>(Wl + (16 * w + i) * TS + 16 * kq + 4 * m + 4);
+        float4 b0, b1;
+        if (WT) {
+            const float* bp = Wl + (16 * kq + 4 * m) * TS + 16 * w + i;
+            b0 = make_float4(bp[0], bp[TS], bp[2 * TS], bp[3 * TS]);
+            b1 = make_float4(bp[4 * TS], bp[5 * TS], bp[6 * TS], bp[7 * TS]);
+        } else {
+            b0 = *reinterpret_cast<const float4*>(Wl + (16 * w + i) * TS + 16 * kq + 4 * m);
+            b1 = *reinterpret_cast<const float4*>(Wl + (16 * w + i) * TS + 16 * kq + 4 * m + 4);
+        }
         const float4 a0 = *reinterpret_cast<const float4*>(Tin + i * TS + 16 * kq + 4 * m);
         const float4 a1 = *reinterpret_cast<const float4*>(Tin + i * TS + 16 * kq + 4 * m + 4);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);

@@ -121,6 +121,10 @@ if __name__ == "__main__":
         single("config0-like karate-size, B=1 (monitorer-sim batch_size)", 34, 78, 1, 64, 20, 40)
         single("dolphins-size, B=4", 62, 159, 4, 64, 20, 40)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mid":
+        single("config1-like fb-social-size, B=1", 1893, 13835, 1, 64, 30, 20)
+        single("config2-like wiki-vote-size, B=1", 7066, 100736, 1, 64, 30, 10)
+        sys.exit(0)
     single("config0-like karate-size, B=1 (monitorer-sim batch_size)", 34, 78, 1, 64, 20, 20)
     single("config1-like fb-social-size, B=1", 1893, 13835, 1, 64, 30, 10)
     single("config1-like fb-social-size, B=8", 1893, 13835, 8, 64, 30, 10)
