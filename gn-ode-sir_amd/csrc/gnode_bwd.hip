@@ -315,27 +315,40 @@ __global__ __launch_bounds__(256) void k_mlp64_q(const float* __restrict__ X, co
     }
 }
 
-// two tables gathered through the same neighbour list (AI = A Z_I, Gq = A q), ascending column order
+// two tables gathered through the same neighbour list (AI = A Z_I, Gq = A q), ascending column order.
+// NB neighbours (2 NB row loads) are in flight per lane group.
+template <int NB = 2>
 __device__ __forceinline__ void gather2_row64(const int* __restrict__ rowptr, const int* __restrict__ col,
                                               const float* __restrict__ T0, const float* __restrict__ T1, int node,
                                               bool valid, int sub, float4& acc0, float4& acc1) {
     acc0 = zero4(); acc1 = zero4();
     int start = 0, end = 0;
     if (valid) { start = rowptr[node]; end = rowptr[node + 1]; }
+    const unsigned lane_b = 16u * sub;
     for (int e0 = start; e0 < end; e0 += 16) {
         const int cnt = min(16, end - e0);
-        const int mine = (sub < cnt) ? col[e0 + sub] : 0;
+        const unsigned mine = (sub < cnt) ? (unsigned)col[e0 + sub] * 256u : 0u;     // byte offset of the neighbour row
+#define GN_LD2(K, U, V)                                                                            \
+            float4 U = zero4(), V = zero4();                                                       \
+            if (K < cnt) { const unsigned o = (unsigned)row_bcast<(K) & 15>((int)mine) + lane_b; U = ld4o(T0, o); V = ld4o(T1, o); }
+#define GN_AC2(U, V)                                                                               \
+            acc0.x += U.x; acc0.y += U.y; acc0.z += U.z; acc0.w += U.w;                            \
+            acc1.x += V.x; acc1.y += V.y; acc1.z += V.z; acc1.w += V.w;
 #define GN_G2(J)                                                                                   \
         if (J < cnt) {                                                                             \
-            const size_t o0 = (size_t)row_bcast<J>(mine) * 64 + 4 * sub;                           \
-            float4 u0 = ld4g(T0 + o0), v0 = ld4g(T1 + o0), u1 = zero4(), v1 = u1;                  \
-            if (J + 1 < cnt) { const size_t o1 = (size_t)row_bcast<J + 1>(mine) * 64 + 4 * sub; u1 = ld4g(T0 + o1); v1 = ld4g(T1 + o1); } \
-            acc0.x += u0.x; acc0.y += u0.y; acc0.z += u0.z; acc0.w += u0.w;                        \
-            acc1.x += v0.x; acc1.y += v0.y; acc1.z += v0.z; acc1.w += v0.w;                        \
-            acc0.x += u1.x; acc0.y += u1.y; acc0.z += u1.z; acc0.w += u1.w;                        \
-            acc1.x += v1.x; acc1.y += v1.y; acc1.z += v1.z; acc1.w += v1.w;                        \
+            GN_LD2(J, u0, v0) GN_LD2(J + 1, u1, v1)                                                \
+            GN_AC2(u0, v0) GN_AC2(u1, v1)                                                          \
         }
-        GN_G2(0) GN_G2(2) GN_G2(4) GN_G2(6) GN_G2(8) GN_G2(10) GN_G2(12) GN_G2(14)
+#define GN_G4(J)                                                                                   \
+        if (J < cnt) {                                                                             \
+            GN_LD2(J, u0, v0) GN_LD2(J + 1, u1, v1) GN_LD2(J + 2, u2, v2) GN_LD2(J + 3, u3, v3)    \
+            GN_AC2(u0, v0) GN_AC2(u1, v1) GN_AC2(u2, v2) GN_AC2(u3, v3)                            \
+        }
+        if (NB == 2) { GN_G2(0) GN_G2(2) GN_G2(4) GN_G2(6) GN_G2(8) GN_G2(10) GN_G2(12) GN_G2(14) }
+        else { GN_G4(0) GN_G4(4) GN_G4(8) GN_G4(12) }
+#undef GN_G4
+#undef GN_AC2
+#undef GN_LD2
 #undef GN_G2
     }
 }
@@ -454,6 +467,10 @@ __global__ __launch_bounds__(256) void k_bwd_step64(const int* __restrict__ rowp
 #ifndef GN_BWD_RPG1_OCC
 #define GN_BWD_RPG1_OCC 3
 #endif
+#ifndef GN_BWD_NB
+#define GN_BWD_NB 4          // neighbours in flight per lane group in the fused kernel's two-table gather (2: 473 us per
+                             // interval on the 75k graph x 4, 4: 456 us; mid-size train steps -5 %)
+#endif
 static_assert(GN_BWD_RPG1_OCC * 256 <= BWD_NWG, "fused backward grid exceeds the partial-gradient slots");
 template <int OCC, int RPG>
 __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
@@ -510,7 +527,7 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
                 ai = ld4g(AIhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
                 gq = ld4g(GQhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
             } else {
-                gather2_row64(rowptr, col, ZIc + (size_t)base * 64, Qc + (size_t)base * 64, node, valid[p], sub, ai, gq);
+                gather2_row64<GN_BWD_NB>(rowptr, col, ZIc + (size_t)base * 64, Qc + (size_t)base * 64, node, valid[p], sub, ai, gq);
             }
             float4 dS = zero4(), dI = zero4();
             aS[p] = zero4(); aI[p] = zero4(); aR[p] = zero4(); bt[p] = 0.f;
