@@ -19,6 +19,7 @@
 // launches (fixed grid, fixed row->workgroup map); one final kernel sums the slots in
 // order.  No float atomics, bitwise reproducible run to run.
 #include "gnode_bwd.h"
+#include "gnode_gather.h"
 #include "gnode_mfma64.h"
 #include "gnode_head64.h"
 #include <algorithm>
@@ -158,19 +159,7 @@ __global__ __launch_bounds__(256) void k_bwd_gather(const int* __restrict__ rowp
         gq = ld4b(GQhub + ((size_t)blockIdx.y * n_hub + hub) * H + 4 * sub);
     }
     const int start = hub >= 0 ? 0 : rowptr[node], end = hub >= 0 ? 0 : rowptr[node + 1];
-    for (int e0 = start; e0 < end; e0 += LPR) {
-        const int cnt = min(LPR, end - e0);
-        const int mine = (sub < cnt) ? col[e0 + sub] : 0;
-        for (int j = 0; j < cnt; ++j) {
-            const int c = __shfl(mine, j, LPR);
-            if (active) {
-                const float4 v = ld4b(ZI + (size_t)(base + c) * H + 4 * sub);
-                const float4 u = ld4b(q + (size_t)(base + c) * H + 4 * sub);
-                ai.x += v.x; ai.y += v.y; ai.z += v.z; ai.w += v.w;
-                gq.x += u.x; gq.y += u.y; gq.z += u.z; gq.w += u.w;
-            }
-        }
-    }
+    gn_gather2<4>(col, start, end, ZI + (size_t)base * H, q + (size_t)base * H, H, sub, active, ai, gq);
     if (!active) return;
     const float bt = beta[r], gm = gamma[r];
     const float4 aS = ld4b(a + off), aI = ld4b(a + slab + off), aR = ld4b(a + 2 * slab + off);

@@ -13,6 +13,7 @@
 // like the reference's separate torch ops; FMAs are written explicitly where
 // they are wanted (the generic node-MLP inner product).
 #include "gnode_common.h"
+#include "gnode_gather.h"
 #include "gnode_h64.h"
 #include <algorithm>
 #include <cstdlib>
@@ -199,27 +200,7 @@ __global__ __launch_bounds__(256) void k_mlp_generic(const float* __restrict__ X
 template <int LPR>
 __device__ __forceinline__ float4 gather_row(const int* __restrict__ rowptr, const int* __restrict__ col,
                                              const float* __restrict__ ZI_base, int node, int sub, bool active, int H) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int start = rowptr[node], end = rowptr[node + 1];
-    for (int e0 = start; e0 < end; e0 += LPR) {
-        const int cnt = min(LPR, end - e0);
-        const int mine = (sub < cnt) ? col[e0 + sub] : 0;
-        for (int j = 0; j < cnt; j += 4) {
-            const int c0 = __shfl(mine, j, LPR);
-            const int c1 = __shfl(mine, min(j + 1, LPR - 1), LPR);
-            const int c2 = __shfl(mine, min(j + 2, LPR - 1), LPR);
-            const int c3 = __shfl(mine, min(j + 3, LPR - 1), LPR);
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0, v3 = v0;
-            if (active) {
-                v0 = ld4(ZI_base + (size_t)c0 * H + 4 * sub);
-                if (j + 1 < cnt) v1 = ld4(ZI_base + (size_t)c1 * H + 4 * sub);
-                if (j + 2 < cnt) v2 = ld4(ZI_base + (size_t)c2 * H + 4 * sub);
-                if (j + 3 < cnt) v3 = ld4(ZI_base + (size_t)c3 * H + 4 * sub);
-            }
-            acc = add4(acc, v0); acc = add4(acc, v1); acc = add4(acc, v2); acc = add4(acc, v3);
-        }
-    }
-    return acc;
+    return gn_gather1<8>(col, rowptr[node], rowptr[node + 1], ZI_base, H, sub, active);
 }
 
 struct StepOut {
