@@ -674,11 +674,21 @@ __global__ __launch_bounds__(256) void k_enc_bwd(const float* __restrict__ a, co
 
 // Sum the workgroup slots in order and write each parameter's gradient straight to its destination.
 struct GradDst { float* dst[8]; int off[9]; };
+// 16 elements x 16 slot slices per workgroup: slice s sums slots s, s+16, ... in order, then the slices are summed
+// in order through LDS -- a fixed association, so still bitwise reproducible, without 768 serial loads per thread.
 __global__ __launch_bounds__(256) void k_reduce_parts(const float* __restrict__ part_all, int nwg, int total, GradDst gd) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
+    __shared__ float red[16][17];
+    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
     float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += part_all[(size_t)w * total + e];
+    if (e < total)
+        for (int w = slice; w < nwg; w += 16) s += part_all[(size_t)w * total + e];
+    red[slice][el] = s;
+    __syncthreads();
+    if (slice != 0 || e >= total) return;
+    s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += red[q][el];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         if (e >= gd.off[k] && e < gd.off[k + 1]) gd.dst[k][e - gd.off[k]] = s;
@@ -877,7 +887,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     gd.dst[6] = (float*)grads->linearS1_weight;       gd.dst[7] = (float*)grads->linearS1_bias;
     const int offs[9] = {L.oW(), L.ob(), L.ow3(), L.ob3(), L.ow2(), L.ob2(), L.ow1(), L.ob1(), L.total()};
     for (int k = 0; k < 9; ++k) gd.off[k] = offs[k];
-    hipLaunchKernelGGL(k_reduce_parts, dim3((L.total() + 255) / 256), dim3(256), 0, st, part, slots_used, L.total(), gd);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((L.total() + 15) / 16), dim3(256), 0, st, part, slots_used, L.total(), gd);
     GN_LAUNCH_CHECK();
     return 0;
 }

@@ -14,10 +14,13 @@ template <int C>
 __device__ __forceinline__ float4 gn_gather1(const int* __restrict__ col, int start, int end, const float* __restrict__ T,
                                              int H, int sub, bool active) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e0 = start; e0 < end; e0 += C) {
-        int c[C];
+    int c[C];
 #pragma unroll
-        for (int k = 0; k < C; ++k) c[k] = (e0 + k < end) ? col[e0 + k] : -1;
+    for (int k = 0; k < C; ++k) c[k] = (start + k < end) ? col[start + k] : -1;
+    for (int e0 = start; e0 < end; e0 += C) {
+        int cn[C];                                   // ids of the NEXT chunk travel under this chunk's row loads
+#pragma unroll
+        for (int k = 0; k < C; ++k) cn[k] = (e0 + C + k < end) ? col[e0 + C + k] : -1;
         float4 v[C];
 #pragma unroll
         for (int k = 0; k < C; ++k)
@@ -25,6 +28,8 @@ __device__ __forceinline__ float4 gn_gather1(const int* __restrict__ col, int st
                                          : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < C; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+#pragma unroll
+        for (int k = 0; k < C; ++k) c[k] = cn[k];
     }
     return acc;
 }
@@ -33,10 +38,13 @@ __device__ __forceinline__ float4 gn_gather1(const int* __restrict__ col, int st
 template <int C>
 __device__ __forceinline__ void gn_gather2(const int* __restrict__ col, int start, int end, const float* __restrict__ T0,
                                            const float* __restrict__ T1, int H, int sub, bool active, float4& a0, float4& a1) {
-    for (int e0 = start; e0 < end; e0 += C) {
-        int c[C];
+    int c[C];
 #pragma unroll
-        for (int k = 0; k < C; ++k) c[k] = (e0 + k < end) ? col[e0 + k] : -1;
+    for (int k = 0; k < C; ++k) c[k] = (start + k < end) ? col[start + k] : -1;
+    for (int e0 = start; e0 < end; e0 += C) {
+        int cn[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) cn[k] = (e0 + C + k < end) ? col[e0 + C + k] : -1;
         float4 u[C], v[C];
 #pragma unroll
         for (int k = 0; k < C; ++k) {
@@ -50,5 +58,7 @@ __device__ __forceinline__ void gn_gather2(const int* __restrict__ col, int star
             a0.x += u[k].x; a0.y += u[k].y; a0.z += u[k].z; a0.w += u[k].w;
             a1.x += v[k].x; a1.y += v[k].y; a1.z += v[k].z; a1.w += v[k].w;
         }
+#pragma unroll
+        for (int k = 0; k < C; ++k) c[k] = cn[k];
     }
 }
