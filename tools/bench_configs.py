@@ -64,6 +64,7 @@ def single(name, n, m, B, H, maxTime, reps):
     loop = {}
     for mode in (False, True):
         run = Runner(model, 1e-3, maxTime, 0.5, dev, stack=True, use_graphs=mode)
+        xs, ys = run.place(xs, ys)
         run.train_epoch(xs, ys, B, 0); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for ep in range(3):
