@@ -177,6 +177,10 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "avg_launch_us": gather_avg_s * 1e6, "launches": int(gcnt.value),
                      "algorithmic_bytes_per_launch": alg_bytes,
+                     # `achieved` counts every neighbour-row read of the gather (the algorithm's bytes), a part of which
+                     # the L2 serves, so it can exceed the HBM peak; the measured L2<->fabric bytes over the same time:
+                     "traffic_gbps": (traffic / gather_avg_s / 1e9 if traffic and gather_avg_s > 0 else None),
+                     "traffic_frac": (traffic / gather_avg_s / 1e9 / HBM_PEAK_GBS if traffic and gather_avg_s > 0 else None),
                      # north_star's target metric: the SURVEY's edge-gather bytes alone (col + rowptr + neighbour rows + AI),
                      # charged with the WHOLE fused kernel's time, as a fraction of the same peak
                      "edge_gather_only_frac": ((nnz * 4 + (n + 1) * 4 + nnz * H * 4 + n * H * 4) * chunk / gather_avg_s / 1e9 / HBM_PEAK_GBS
