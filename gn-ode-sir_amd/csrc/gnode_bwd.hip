@@ -641,6 +641,188 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
     }
 }
 
+// --------------------------------------------------------------------------- ONE launch per backward interval, H <= 32
+// The generic-H twin of k_bwd_fused64 for the small hidden sizes the multi-graph launcher uses (H = 8,
+// monitorer-ngraphs.py:20): a lane group of LPR = H/4 lanes owns a row; both mat-vecs (g_Y = dpre W, Z = sigmoid(W y + b))
+// broadcast the row inside the group by shuffles against W / W^T staged in LDS, gW += dpre^T y goes through LDS row
+// tiles as in k_bwd_mlp, and the head's VJP at grid point i-1 plus the next interval's Z / q tables are folded in.
+template <int LPR>
+__device__ __forceinline__ float4 group_lin(float4 x, const float* __restrict__ M, int sub, bool active, int H) {
+    float4 acc = z4();
+    const float xv[4] = {x.x, x.y, x.z, x.w};
+    for (int kk = 0; 4 * kk < H; ++kk) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float xk = __shfl(xv[c], kk, LPR);
+            if (active) {
+                const float4 w = ld4b(M + (size_t)(4 * kk + c) * H + 4 * sub);
+                acc.x = fmaf(xk, w.x, acc.x); acc.y = fmaf(xk, w.y, acc.y);
+                acc.z = fmaf(xk, w.z, acc.z); acc.w = fmaf(xk, w.w, acc.w);
+            }
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ float sig_b(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_bwd_fused_generic(
+    const int* __restrict__ rowptr, const int* __restrict__ col, int n, long rows, int H, float* __restrict__ ZS,
+    const float* __restrict__ ZIc, const float* __restrict__ Qc, float* __restrict__ ZIn, float* __restrict__ Qn,
+    const float* __restrict__ Ysol, const float* __restrict__ Yprev, const float* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ beta, const float* __restrict__ gamma, float dt,
+    float* __restrict__ a, float* __restrict__ part_all, const float* __restrict__ gS, const float* __restrict__ gI,
+    const float* __restrict__ gR, const float* __restrict__ w3, const float* __restrict__ b3, const float* __restrict__ w2,
+    const float* __restrict__ b2, const int* __restrict__ hubidx, const float* __restrict__ AIhub,
+    const float* __restrict__ GQhub, int n_hub, int do_next) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int G = 256 / LPR;
+    const PartLayout L{H};
+    float* Wl = lds;                           // W[j][k]
+    float* Wt = Wl + (size_t)H * H;            // W^T
+    float* Dt = Wt + (size_t)H * H;            // [2][G][H] dpre tile (S, I)
+    float* Yt = Dt + (size_t)2 * G * H;        // [2][G][H] y tile   (S, I)
+    for (int idx = threadIdx.x; idx < H * H; idx += 256) {
+        const float v = W[idx];
+        Wl[idx] = v;
+        Wt[(size_t)(idx % H) * H + idx / H] = v;
+    }
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const bool lane_ok = 4 * sub < H;
+    const size_t slab = (size_t)rows * H;
+    const int nE = H * H;
+    constexpr int MAXM = (LPR * LPR / 16) < 1 ? 1 : (LPR * LPR / 16);
+    float accW[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) accW[m] = 0.f;
+    float accb = 0.f;
+    const int M = (nE + 255) / 256;
+    const bool head = gS != nullptr;
+    const float4 bias4 = lane_ok ? ld4b(bias + 4 * sub) : z4();
+    float4 w3v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w3v[k] = lane_ok ? ld4b(w3 + (size_t)k * H + 4 * sub) : z4();
+    HeadAcc hacc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hacc.dw3[k] = z4(); hacc.db3[k] = 0.f; hacc.dw2[k] = 0.f; }
+    hacc.db2 = 0.f;
+    for (long r0 = (long)blockIdx.x * G; r0 < rows; r0 += (long)gridDim.x * G) {
+        const long r = r0 + grp;
+        const bool inrow = r < rows, ok = lane_ok && inrow;
+        const long b = inrow ? r / n : 0;
+        const int node = (int)(r - b * n);
+        const size_t off = (size_t)r * H + 4 * sub;
+        // 1. both gathers (no cross-lane traffic inside, so the tail rows may skip them)
+        float4 ai = z4(), gq = z4();
+        if (inrow) {
+            const int hub = hubidx ? hubidx[node] : -1;
+            if (hub >= 0) {
+                if (lane_ok) {
+                    ai = ld4b(AIhub + ((size_t)b * n_hub + hub) * H + 4 * sub);
+                    gq = ld4b(GQhub + ((size_t)b * n_hub + hub) * H + 4 * sub);
+                }
+            } else {
+                gn_gather2<4>(col, rowptr[node], rowptr[node + 1], ZIc + (size_t)b * n * H, Qc + (size_t)b * n * H, H, sub, lane_ok, ai, gq);
+            }
+        }
+        float4 aS = z4(), aI = z4(), aR = z4(), dS = z4(), dI = z4(), yS = z4(), yI = z4();
+        float bt = 0.f;
+        if (ok) {
+            bt = beta[r];
+            const float gm = gamma[r];
+            aS = ld4b(a + off); aI = ld4b(a + slab + off); aR = ld4b(a + 2 * slab + off);
+            const float4 zs = ld4b(ZS + off), zi = ld4b(ZIc + off);
+#define GN_DPRE(c)                                                         \
+            {                                                              \
+                const float v = bt * (aI.c - aS.c);                        \
+                dS.c = (v * ai.c) * (zs.c * (1.0f - zs.c));                \
+                dI.c = (gq.c + gm * (aR.c - aI.c)) * (zi.c * (1.0f - zi.c)); \
+            }
+            GN_DPRE(x) GN_DPRE(y) GN_DPRE(z) GN_DPRE(w)
+#undef GN_DPRE
+            yS = ld4b(Ysol + off); yI = ld4b(Ysol + slab + off);
+        }
+        __syncthreads();                       // previous tile's gW pass is done with the tiles (also covers the W stage)
+        if (lane_ok) {
+            st4b(Dt + (size_t)grp * H + 4 * sub, dS);       st4b(Dt + ((size_t)G + grp) * H + 4 * sub, dI);
+            st4b(Yt + (size_t)grp * H + 4 * sub, yS);       st4b(Yt + ((size_t)G + grp) * H + 4 * sub, yI);
+        }
+        // 2. g_Y = dpre W (row broadcast inside the lane group), a += dt g_Y
+        const float4 uS = group_lin<LPR>(dS, Wl, sub, lane_ok, H), uI = group_lin<LPR>(dI, Wl, sub, lane_ok, H);
+        aS.x += dt * uS.x; aS.y += dt * uS.y; aS.z += dt * uS.z; aS.w += dt * uS.w;
+        aI.x += dt * uI.x; aI.y += dt * uI.y; aI.z += dt * uI.z; aI.w += dt * uI.w;
+        // 3. dL/dsol[i-1] through the head (rows beyond the end carry y = 0, gout = 0)
+        float4 y[3] = {z4(), z4(), z4()};
+        float gout[3] = {0.f, 0.f, 0.f};
+        if (ok && (head || do_next)) { y[0] = ld4b(Yprev + off); y[1] = ld4b(Yprev + slab + off); }
+        if (head) {
+            if (ok) y[2] = ld4b(Yprev + 2 * slab + off);
+            if (inrow) { gout[0] = gS[r]; gout[1] = gI[r]; gout[2] = gR[r]; }
+            head_vjp64<LPR>(y, gout, w3v, b3, w2, b2, aS, aI, aR, hacc);
+            if (ok) st4b(a + 2 * slab + off, aR);
+        }
+        if (ok) { st4b(a + off, aS); st4b(a + slab + off, aI); }
+        // 4. Z(y_{i-1}) and q for the next interval
+        if (do_next) {
+            float4 zs = group_lin<LPR>(y[0], Wt, sub, lane_ok, H), zi = group_lin<LPR>(y[1], Wt, sub, lane_ok, H);
+            zs = make_float4(sig_b(zs.x + bias4.x), sig_b(zs.y + bias4.y), sig_b(zs.z + bias4.z), sig_b(zs.w + bias4.w));
+            zi = make_float4(sig_b(zi.x + bias4.x), sig_b(zi.y + bias4.y), sig_b(zi.z + bias4.z), sig_b(zi.w + bias4.w));
+            if (ok) {
+                st4b(ZS + off, zs); st4b(ZIn + off, zi);
+                st4b(Qn + off, make_float4(bt * (aI.x - aS.x) * zs.x, bt * (aI.y - aS.y) * zs.y, bt * (aI.z - aS.z) * zs.z,
+                                           bt * (aI.w - aS.w) * zs.w));
+            }
+        }
+        __syncthreads();                       // tiles complete
+        // 5. gW[j][k] += sum_rows dpre[r][j] * y[r][k]   (thread owns entries e = tid + 256 m), gb += column sums
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) {
+            if (m < M) {
+                const int e = threadIdx.x + 256 * m;
+                if (e < nE) {
+                    const int j = e / H, k = e % H;
+                    float s = 0.f;
+                    for (int rr = 0; rr < 2 * G; ++rr) s = fmaf(Dt[(size_t)rr * H + j], Yt[(size_t)rr * H + k], s);
+                    accW[m] += s;
+                }
+            }
+        }
+        if (threadIdx.x < H) {
+            float s = 0.f;
+            for (int rr = 0; rr < 2 * G; ++rr) s += Dt[(size_t)rr * H + threadIdx.x];
+            accb += s;
+        }
+    }
+    float* part = part_all + (size_t)blockIdx.x * L.total();
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+        if (m < M) {
+            const int e = threadIdx.x + 256 * m;
+            if (e < nE) part[L.oW() + e] += dt * accW[m];
+        }
+    }
+    if (threadIdx.x < H) part[L.ob() + threadIdx.x] += dt * accb;
+    if (head) {
+        __syncthreads();
+        const int ne = 4 * H + 12;                 // 4H + 9 used; rows stay 16-B aligned
+        float* mine = lds + (size_t)grp * ne;
+        if (lane_ok)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) st4b(mine + k * H + 4 * sub, hacc.dw3[k]);
+        if (sub == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mine[4 * H + k] = hacc.db3[k]; mine[4 * H + 4 + k] = hacc.dw2[k]; }
+            mine[4 * H + 8] = hacc.db2;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 4 * H + 9; e += 256) {
+            float s = 0.f;
+            for (int gi = 0; gi < G; ++gi) s += lds[(size_t)gi * ne + e];
+            part[L.ow3() + e] += s;
+        }
+    }
+}
+
 // --------------------------------------------------------------------------- encoder backward
 template <int LPR>
 __global__ __launch_bounds__(256) void k_enc_bwd(const float* __restrict__ a, const float* __restrict__ sol0,
@@ -827,6 +1009,32 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                                dt_host[i - 1], a, part, gSs, s >= 0 ? gI + (size_t)s * rows : nullptr,
                                s >= 0 ? gR + (size_t)s * rows : nullptr, p->linear3_weight, p->linear3_bias,
                                p->linearS2_weight, p->linearS2_bias, g->hubidx, AIhub, GQhub, g->n_hub, i > 1 ? 1 : 0);
+            GN_LAUNCH_CHECK();
+        }
+    } else if (H <= 32 && fuse64 && n_steps >= 1) {
+        // small hidden sizes: the same one-launch-per-interval scheme on lane groups (k_bwd_fused_generic)
+        float* ZS = Z; float* ZIb[2] = {Z + slab, dpre};
+        float* Qb[2] = {q, dpre + slab};
+        const float* yl = sol + (size_t)(G - 1) * 4 * slab;
+        if (int e = gn_launch_mlp_any(yl, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
+        hipLaunchKernelGGL(k_bwd_q, dim3(2048), dim3(256), 0, st, a, Z, beta, q, (long)rows, H);
+        GN_LAUNCH_CHECK();
+        const size_t fl = std::max((size_t)2 * H * H + (size_t)4 * rpw * H, (size_t)rpw * (4 * H + 12));
+        const int grid = (int)std::min<long>(BWD_NWG, std::max<long>(1, (rows + rpw - 1) / rpw));
+        slots_used = std::max(slots_used, grid);
+        for (int i = G - 1; i >= 1; --i) {
+            const int cur = (G - 1 - i) & 1;
+            const float *AIhub = nullptr, *GQhub = nullptr;
+            if (int e = gn_hub_gather(g, rows / g->n, H, ZIb[cur], Qb[cur], &AIhub, &GQhub, st)) return e;
+            const int s = slot_of(i - 1);
+            BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_bwd_fused_generic<LPR>, dim3(grid), dim3(256), fl * sizeof(float), st, g->rowptr,
+                                                 g->col, g->n, (long)rows, H, ZS, ZIb[cur], Qb[cur], ZIb[cur ^ 1], Qb[cur ^ 1],
+                                                 sol + (size_t)i * 4 * slab, sol + (size_t)(i - 1) * 4 * slab,
+                                                 p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma, dt_host[i - 1], a,
+                                                 part, s >= 0 ? gS + (size_t)s * rows : nullptr,
+                                                 s >= 0 ? gI + (size_t)s * rows : nullptr, s >= 0 ? gR + (size_t)s * rows : nullptr,
+                                                 p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias,
+                                                 g->hubidx, AIhub, GQhub, g->n_hub, i > 1 ? 1 : 0));
             GN_LAUNCH_CHECK();
         }
     } else

@@ -1,4 +1,4 @@
-// VJP of the read-out head for H = 64 rows held by 16-lane groups (shared by the backward kernels).
+// VJP of the read-out head for rows held by LPR-lane groups, 4 features per lane (shared by the backward kernels).
 #pragma once
 #include "gnode_mfma64.h"
 
@@ -10,7 +10,17 @@ struct HeadAcc {
     float db3[4], dw2[4], db2;
 };
 
+// sum over the LPR lanes that hold one row: a DPP row reduction for 16-lane groups, xor-shuffles otherwise
+template <int LPR>
+__device__ __forceinline__ float head_rowsum(float v) {
+    if (LPR == 16) return row_sum16(v);
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, LPR);
+    return v;
+}
+
 // VJP of softmax(linearS2(relu(linear3(y_X)))) at one row (reference ode_nn_ngraph_sim.py:172-187): a_X += dL/dy_X
+template <int LPR = 16>
 __device__ __forceinline__ void head_vjp64(const float4 (&y)[3], const float (&gout)[3], const float4 (&w3v)[4],
                                            const float* __restrict__ b3, const float* __restrict__ w2,
                                            const float* __restrict__ b2, float4& aS, float4& aI, float4& aR, HeadAcc& acc) {
@@ -20,7 +30,7 @@ __device__ __forceinline__ void head_vjp64(const float4 (&y)[3], const float (&g
         q[X] = b2[0];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            p3[X][k] = row_sum16(dot4t(w3v[k], y[X])) + b3[k];
+            p3[X][k] = head_rowsum<LPR>(dot4t(w3v[k], y[X])) + b3[k];
             q[X] = fmaf(w2[k], fmaxf(p3[X][k], 0.f), q[X]);
         }
     }
