@@ -510,6 +510,17 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
             const int node = tile * TR + lr[p];
             valid[p] = node < n;
             off[p] = (size_t)(base + node) * 64 + 4 * sub;
+            // own-row loads first: they travel under the gather's dependent id -> row round trips
+            float4 dS = zero4(), dI = zero4(), zs = zero4(), zi = zero4(), ysr = zero4(), yir = zero4();
+            float gm = 0.f;
+            aS[p] = zero4(); aI[p] = zero4(); aR[p] = zero4(); bt[p] = 0.f;
+            if (valid[p]) {
+                bt[p] = beta[base + node];
+                gm = gamma[base + node];
+                aS[p] = ld4g(a + off[p]); aI[p] = ld4g(a + slab + off[p]); aR[p] = ld4g(a + 2 * slab + off[p]);
+                zs = ld4g(ZS + off[p]); zi = ld4g(ZIc + off[p]);
+                ysr = ld4g(Ysol + off[p]); yir = ld4g(Ysol + slab + off[p]);
+            }
             float4 ai, gq;
             const int hub = (hubidx && valid[p]) ? hubidx[node] : -1;
             if (hub >= 0) {
@@ -518,13 +529,7 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
             } else {
                 gather2_row64<GN_BWD_NB>(rowptr, col, ZIc + (size_t)base * 64, Qc + (size_t)base * 64, node, valid[p], sub, ai, gq);
             }
-            float4 dS = zero4(), dI = zero4();
-            aS[p] = zero4(); aI[p] = zero4(); aR[p] = zero4(); bt[p] = 0.f;
             if (valid[p]) {
-                bt[p] = beta[base + node];
-                const float gm = gamma[base + node];
-                aS[p] = ld4g(a + off[p]); aI[p] = ld4g(a + slab + off[p]); aR[p] = ld4g(a + 2 * slab + off[p]);
-                const float4 zs = ld4g(ZS + off[p]), zi = ld4g(ZIc + off[p]);
 #define GN_DP(c)                                                               \
                 {                                                              \
                     const float v = bt[p] * (aI[p].c - aS[p].c);               \
@@ -536,8 +541,8 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
             }
             *reinterpret_cast<float4*>(&Dt[0][lr[p] * TS + 4 * sub]) = dS;
             *reinterpret_cast<float4*>(&Dt[1][lr[p] * TS + 4 * sub]) = dI;
-            *reinterpret_cast<float4*>(&Yt[0][lr[p] * TS + 4 * sub]) = valid[p] ? ld4g(Ysol + off[p]) : zero4();
-            *reinterpret_cast<float4*>(&Yt[1][lr[p] * TS + 4 * sub]) = valid[p] ? ld4g(Ysol + slab + off[p]) : zero4();
+            *reinterpret_cast<float4*>(&Yt[0][lr[p] * TS + 4 * sub]) = ysr;
+            *reinterpret_cast<float4*>(&Yt[1][lr[p] * TS + 4 * sub]) = yir;
         }
         __syncthreads();
 #pragma unroll
@@ -712,7 +717,16 @@ __global__ __launch_bounds__(256) void k_bwd_fused_generic(
         const long b = inrow ? r / n : 0;
         const int node = (int)(r - b * n);
         const size_t off = (size_t)r * H + 4 * sub;
-        // 1. both gathers (no cross-lane traffic inside, so the tail rows may skip them)
+        // 1. own-row loads first (they travel under the gathers' dependent round trips), then both gathers (no
+        //    cross-lane traffic inside, so the tail rows may skip them)
+        float4 aS = z4(), aI = z4(), aR = z4(), dS = z4(), dI = z4(), yS = z4(), yI = z4(), zs0 = z4(), zi0 = z4();
+        float bt = 0.f, gm = 0.f;
+        if (ok) {
+            bt = beta[r]; gm = gamma[r];
+            aS = ld4b(a + off); aI = ld4b(a + slab + off); aR = ld4b(a + 2 * slab + off);
+            zs0 = ld4b(ZS + off); zi0 = ld4b(ZIc + off);
+            yS = ld4b(Ysol + off); yI = ld4b(Ysol + slab + off);
+        }
         float4 ai = z4(), gq = z4();
         if (inrow) {
             const int hub = hubidx ? hubidx[node] : -1;
@@ -722,25 +736,18 @@ __global__ __launch_bounds__(256) void k_bwd_fused_generic(
                     gq = ld4b(GQhub + ((size_t)b * n_hub + hub) * H + 4 * sub);
                 }
             } else {
-                gn_gather2<4>(col, rowptr[node], rowptr[node + 1], ZIc + (size_t)b * n * H, Qc + (size_t)b * n * H, H, sub, lane_ok, ai, gq);
+                gn_gather2<(LPR <= 4 ? 8 : 4)>(col, rowptr[node], rowptr[node + 1], ZIc + (size_t)b * n * H, Qc + (size_t)b * n * H, H, sub, lane_ok, ai, gq);
             }
         }
-        float4 aS = z4(), aI = z4(), aR = z4(), dS = z4(), dI = z4(), yS = z4(), yI = z4();
-        float bt = 0.f;
         if (ok) {
-            bt = beta[r];
-            const float gm = gamma[r];
-            aS = ld4b(a + off); aI = ld4b(a + slab + off); aR = ld4b(a + 2 * slab + off);
-            const float4 zs = ld4b(ZS + off), zi = ld4b(ZIc + off);
 #define GN_DPRE(c)                                                         \
             {                                                              \
                 const float v = bt * (aI.c - aS.c);                        \
-                dS.c = (v * ai.c) * (zs.c * (1.0f - zs.c));                \
-                dI.c = (gq.c + gm * (aR.c - aI.c)) * (zi.c * (1.0f - zi.c)); \
+                dS.c = (v * ai.c) * (zs0.c * (1.0f - zs0.c));              \
+                dI.c = (gq.c + gm * (aR.c - aI.c)) * (zi0.c * (1.0f - zi0.c)); \
             }
             GN_DPRE(x) GN_DPRE(y) GN_DPRE(z) GN_DPRE(w)
 #undef GN_DPRE
-            yS = ld4b(Ysol + off); yI = ld4b(Ysol + slab + off);
         }
         __syncthreads();                       // previous tile's gW pass is done with the tiles (also covers the W stage)
         if (lane_ok) {

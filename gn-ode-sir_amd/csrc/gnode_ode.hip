@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void k_mlp_generic(const float* __restrict__ X
 template <int LPR>
 __device__ __forceinline__ float4 gather_row(const int* __restrict__ rowptr, const int* __restrict__ col,
                                              const float* __restrict__ ZI_base, int node, int sub, bool active, int H) {
-    return gn_gather1<8>(col, rowptr[node], rowptr[node + 1], ZI_base, H, sub, active);
+    // small lane groups have registers to spare: more rows in flight, fewer dependent round trips per row
+    return gn_gather1<(LPR <= 4 ? 16 : 8)>(col, rowptr[node], rowptr[node + 1], ZI_base, H, sub, active);
 }
 
 struct StepOut {
@@ -303,14 +304,15 @@ __global__ __launch_bounds__(256) void k_step_generic(const int* __restrict__ ro
     const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 bias4 = active ? ld4(bias + 4 * sub) : z0;
 
+    // own-row loads first: they travel under the gather's dependent id -> row round trips instead of after them
+    float4 yS = z0, yI = z0, yR = z0, zi = z0;
+    if (active) { yS = ld4(Y + off); yI = ld4(Y + slab + off); yR = ld4(Y + 2 * slab + off); zi = ld4(ZI + off); }
+    const float nb = -beta[r], gm = gamma[r];
     const int hub = hubidx ? hubidx[node] : -1;
     float4 ai;
     if (hub >= 0) ai = active ? ld4(AIhub + ((size_t)blockIdx.y * n_hub + hub) * H + 4 * sub) : z0;
     else ai = gather_row<LPR>(rowptr, col, ZI + (size_t)base * H, node, sub, active, H);
-    float4 yS = z0, yI = z0, yR = z0, zi = z0;
-    if (active) { yS = ld4(Y + off); yI = ld4(Y + slab + off); yR = ld4(Y + 2 * slab + off); zi = ld4(ZI + off); }
     const float4 zs = group_mlp<LPR>(yS, Wt, bias4, sub, active, H);
-    const float nb = -beta[r], gm = gamma[r];
     float4 dS, dI, dR;
     dS.x = nb * (ai.x * zs.x); dS.y = nb * (ai.y * zs.y); dS.z = nb * (ai.z * zs.z); dS.w = nb * (ai.w * zs.w);
     dR.x = gm * zi.x; dR.y = gm * zi.y; dR.z = gm * zi.z; dR.w = gm * zi.w;
