@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void k_bwd_mlp(const float* __restrict__ dpre,
         __syncthreads();                       // previous tile fully consumed (also covers the W stage)
 #pragma unroll
         for (int X = 0; X < 2; ++X) {
+            if (!lane_ok) continue;            // idle lanes of a group (H/4 not a power of two) would write into the next row
             st4b(Dt + ((size_t)X * G + grp) * H + 4 * sub, ok ? ld4b(dpre + X * slab + off) : z4());
             st4b(Yt + ((size_t)X * G + grp) * H + 4 * sub, ok ? ld4b(Ysol + X * slab + off) : z4());
         }
