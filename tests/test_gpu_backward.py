@@ -147,3 +147,50 @@ def test_forward_and_backward_are_bitwise_reproducible(dev):
         assert torch.equal(a, b)
     for k in runs[0][3]:
         assert torch.equal(runs[0][3][k], runs[1][3][k]), k
+
+
+def test_randomized_backward_configurations(dev):
+    """Seeded sweep over the backward's path boundaries: node counts around the one-launch limit (64) and the tile
+    sizes, every H class (one-launch generic H <= 32, H = 64, five-launch 32 < H != 64, lane groups with idle
+    lanes), hub rows, arbitrary out_rows subsets, several samples."""
+    import torch
+    import gnode_oracle as O
+    from gnode import ops
+    from gnode.graph import DeviceGraph
+    rng = np.random.default_rng(77)
+    n_choices = [3, 15, 16, 17, 33, 63, 64, 65, 100, 140]
+    for case in range(18):
+        n = int(rng.choice(n_choices))
+        H = int(rng.choice([4, 8, 12, 20, 32, 40, 64, 64, 64, 128]))
+        B = int(rng.integers(1, 4))
+        maxTime = int(rng.integers(1, 5))
+        deltaT = float(rng.choice([0.25, 0.5, 1.0]))
+        m = int(rng.integers(0, 3 * n))
+        edges = [(int(a), int(b)) for a, b in rng.integers(0, n, size=(m, 2))]
+        if n >= 100 and case % 2 == 0:
+            edges += [(0, j) for j in range(1, 98)]                # a hub row just above the threshold
+        rp, ci = O.csr_from_edges(n, edges) if edges else (np.zeros(n + 1, np.int32), np.zeros(0, np.int32))
+        P = O.init_params(H, seed=100 + case)
+        x = O.make_samples(n, B, H, seed=case, n_seeds=1)
+        grid = O.time_grid(maxTime, deltaT)
+        G = len(grid)
+        sel = np.sort(rng.choice(G, size=int(rng.integers(1, G + 1)), replace=False)).astype(np.int32) if case % 3 else None
+        n_out = G if sel is None else len(sel)
+        gs = [rng.normal(size=(n_out, B * n)).astype(np.float32) for _ in range(3)]
+        want = O.adjoint_grads_torch(x, P, rp, ci, maxTime, deltaT, *gs, out_rows=sel, dtype="float64")
+        g = DeviceGraph(rp, ci)
+        params = {k: torch.from_numpy(v).to(dev) for k, v in P.items()}
+        x2d = torch.from_numpy(x).to(dev).reshape(B * n, 3 + H)
+        dts = ops.step_sizes(grid)
+        _, _, _, sol = ops.forward(g, x2d, params, dts, "euler", sel, want_sol=True)
+        got = ops.backward(g, x2d, params, dts, "euler", sel, sol, *[torch.from_numpy(a).to(dev) for a in gs])
+        tag = f"case {case}: n={n} H={H} B={B} T={maxTime} dT={deltaT} sel={None if sel is None else sel.tolist()} nnz={len(ci)}"
+        scale = max(float(np.abs(want[k]).max()) for k in want)
+        for k in want:
+            if k == "linearS2.bias":
+                continue
+            # relative to the parameter's own largest gradient, with a floor at 1e-3 of the overall scale for
+            # parameters whose gradient is (nearly) zero in a degenerate case (e.g. no edges)
+            den = max(float(np.abs(want[k]).max()), 1e-3 * scale) + 1e-30
+            err = float(np.max(np.abs(got[k].cpu().numpy().astype(np.float64) - want[k]))) / den
+            assert err <= 2e-4, f"{tag}: {k} rel err {err:.2e}"
