@@ -14,6 +14,11 @@
 // The Jacobians are evaluated at the RIGHT endpoint y_i (one Euler step of the augmented
 // system from t_i to t_{i-1}), which is what the reference's training gradients are.
 //
+// Launch structure: H = 64 and H <= 32 take ONE launch per interval (k_bwd_fused64 / k_bwd_fused_generic: the
+// interval's VJPs, the head's VJP at grid point i-1 and the NEXT interval's Z / q gather tables, double-buffered);
+// graphs with n <= 64 at H = 64 take one launch for the whole sweep (gnode_bwd_tiny.hip); other H: five launches
+// per interval (k_mlp_generic, k_bwd_q, k_bwd_gather, k_bwd_mlp, k_head_bwd).
+//
 // Parameter gradients are reduced deterministically: every workgroup owns one slot of a
 // partial buffer [NWG][NP] that it updates with plain read-modify-writes across all
 // launches (fixed grid, fixed row->workgroup map); one final kernel sums the slots in

@@ -1,14 +1,15 @@
 // H = 64 fast path of the GN-ODE step for MI355X (gfx950).
 //
 // One launch per Euler step (per chunk of samples):
-//   k_step64<FUSE>  persistent 256-thread workgroups walk 32-node tiles:
+//   k_step64<FUSE,PRJ,RPG>  persistent 256-thread workgroups walk 16-node tiles (RPG = 1, 5 workgroups per
+//                           CU; RPG = 2: 32-node tiles, 4 per CU):
 //     P1  stage the tile's Y_S rows to LDS (coalesced 16 B/lane, 4 rows per wave
 //         instruction) and pull-gather AI = sum_{c in adj} Z_I[c] with one 16-lane
 //         group per row (column indices broadcast inside the group by DPP
-//         row_newbcast, neighbour rows as 256-B coalesced reads);
+//         row_newbcast, neighbour rows as 256-B coalesced reads, 8 in flight);
 //     P2  Z_S = sigmoid(Y_S W^T + b) on the fp32 matrix cores
 //         (v_mfma_f32_16x16x4_f32, exact fp32), W^T resident in LDS for the
-//         whole launch, each wave a 32x16 slab of the tile's output;
+//         whole launch, each wave a 16-column slab of the tile's output;
 //     P3  SIR derivative + Euler update of Y_S, Y_I, Y_R in place, optional
 //         trajectory write, fused read-out head + 3-way softmax (16-lane DPP
 //         reductions, no LDS traffic);
