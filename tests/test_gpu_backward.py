@@ -37,6 +37,9 @@ def _rel(a, b):
     (30, 60, 2, 4, 3, 0.5, False),         # H = 4: one lane per row in the generic one-launch backward
     (30, 60, 2, 24, 3, 0.5, True),         # H = 24: lane groups of 8 with two idle lanes
     (50, 150, 2, 48, 3, 0.5, False),       # 32 < H != 64: the five-launch generic backward
+    # more tiles / row blocks than persistent workgroups: accumulators carried across a workgroup's tiles
+    (7000, 30000, 2, 64, 2, 0.5, False),
+    (60000, 150000, 2, 8, 2, 0.5, True),
 ])
 def test_param_grads_vs_oracle(n, m, B, H, maxTime, deltaT, sub, dev, skewed=False):
     import torch
