@@ -365,69 +365,68 @@ __global__ __launch_bounds__(768) void k_tiny64(const int* __restrict__ rowptr, 
 #pragma unroll
         for (int p = 0; p < 2; ++p)
             if (lrow[p] - t * TILE_ROWS >= 16) *reinterpret_cast<float4*>(T2 + (lrow[p] - t * TILE_ROWS) * TS + 4 * sub) = zero4();
+    // The rows' state lives in the owner lanes' REGISTERS across all steps; the LDS tiles YS / YI are only the MFMA
+    // operands.  Per step: gather + SIR update + read-out (row-local), barrier, both node MLPs of the NEXT step
+    // back to back on the matrix cores (Z_S' -> T2, Z_I' -> straight into the other gather table), barrier.
+    float4 ys[2], yi[2], yr[2], pr[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        ys[p] = *reinterpret_cast<const float4*>(YS + lrow[p] * TS + 4 * sub);
+        yi[p] = *reinterpret_cast<const float4*>(YI + lrow[p] * TS + 4 * sub);
+        yr[p] = PRJ ? zero4() : *reinterpret_cast<const float4*>(YR + lrow[p] * TS + 4 * sub);
+        pr[p] = PRJ ? *reinterpret_cast<const float4*>(YR + lrow[p] * 4) : zero4();
+    }
+    if (blk2) mfma_tile<true>(YS + t * tile_f, Wl, T2, bias_l, w, lane);      // Z_S of step 0
+    else mfma_tile16<true>(YS + t * tile_f, Wl, T2, bias_l, w, lane);
+    __syncthreads();
     for (int k = 0; k < sched.n_steps; ++k) {
         const float dt = sched.dt[k];
         const int slot = sched.slot[k];
         float* solk = sol ? sol + (size_t)(k + 1) * 4 * slab : nullptr;
-        float4 ai[2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) ai[p] = gather_row_lds(col, Zc, e_lo[p], e_hi[p], first16[p], sub);
-        if (blk2) mfma_tile<true>(YS + t * tile_f, Wl, T2, bias_l, w, lane);
-        else mfma_tile16<true>(YS + t * tile_f, Wl, T2, bias_l, w, lane);
-        __syncthreads();
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
+            const float4 ai = gather_row_lds(col, Zc, e_lo[p], e_hi[p], first16[p], sub);
             const int lr = lrow[p] - t * TILE_ROWS;
             const float4 zs = *reinterpret_cast<const float4*>(T2 + lr * TS + 4 * sub);
             const float4 zi = *reinterpret_cast<const float4*>(Zc + lrow[p] * TS + 4 * sub);
-            float4 ys = *reinterpret_cast<const float4*>(YS + lrow[p] * TS + 4 * sub);
-            float4 yi = *reinterpret_cast<const float4*>(YI + lrow[p] * TS + 4 * sub);
             float4 dS, dI, dR;
-            dS.x = nb[p] * (ai[p].x * zs.x); dS.y = nb[p] * (ai[p].y * zs.y); dS.z = nb[p] * (ai[p].z * zs.z); dS.w = nb[p] * (ai[p].w * zs.w);
+            dS.x = nb[p] * (ai.x * zs.x); dS.y = nb[p] * (ai.y * zs.y); dS.z = nb[p] * (ai.z * zs.z); dS.w = nb[p] * (ai.w * zs.w);
             dR.x = gm[p] * zi.x; dR.y = gm[p] * zi.y; dR.z = gm[p] * zi.z; dR.w = gm[p] * zi.w;
             dI.x = -dS.x - dR.x; dI.y = -dS.y - dR.y; dI.z = -dS.z - dR.z; dI.w = -dS.w - dR.w;
-            ys.x += dt * dS.x; ys.y += dt * dS.y; ys.z += dt * dS.z; ys.w += dt * dS.w;
-            yi.x += dt * dI.x; yi.y += dt * dI.y; yi.z += dt * dI.z; yi.w += dt * dI.w;
-            *reinterpret_cast<float4*>(YS + lrow[p] * TS + 4 * sub) = ys;
-            *reinterpret_cast<float4*>(YI + lrow[p] * TS + 4 * sub) = yi;
-            float4 yr = zero4();
+            ys[p].x += dt * dS.x; ys[p].y += dt * dS.y; ys[p].z += dt * dS.z; ys[p].w += dt * dS.w;
+            yi[p].x += dt * dI.x; yi[p].y += dt * dI.y; yi[p].z += dt * dI.z; yi[p].w += dt * dI.w;
+            *reinterpret_cast<float4*>(YS + lrow[p] * TS + 4 * sub) = ys[p];
+            *reinterpret_cast<float4*>(YI + lrow[p] * TS + 4 * sub) = yi[p];
             float prj[4] = {0.f, 0.f, 0.f, 0.f};
             if (PRJ) {
-                const float4 pr = *reinterpret_cast<const float4*>(YR + lrow[p] * 4);
                 float4 w3r[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w3r[q] = ld4g(w3 + q * 64 + 4 * sub);
-                prj[0] = pr.x + dt * (gm[p] * row_sum16(fmaf(w3r[0].x, zi.x, fmaf(w3r[0].y, zi.y, fmaf(w3r[0].z, zi.z, w3r[0].w * zi.w)))));
-                prj[1] = pr.y + dt * (gm[p] * row_sum16(fmaf(w3r[1].x, zi.x, fmaf(w3r[1].y, zi.y, fmaf(w3r[1].z, zi.z, w3r[1].w * zi.w)))));
-                prj[2] = pr.z + dt * (gm[p] * row_sum16(fmaf(w3r[2].x, zi.x, fmaf(w3r[2].y, zi.y, fmaf(w3r[2].z, zi.z, w3r[2].w * zi.w)))));
-                prj[3] = pr.w + dt * (gm[p] * row_sum16(fmaf(w3r[3].x, zi.x, fmaf(w3r[3].y, zi.y, fmaf(w3r[3].z, zi.z, w3r[3].w * zi.w)))));
-                if (sub == 0) *reinterpret_cast<float4*>(YR + lrow[p] * 4) = make_float4(prj[0], prj[1], prj[2], prj[3]);
+                prj[0] = pr[p].x + dt * (gm[p] * row_sum16(fmaf(w3r[0].x, zi.x, fmaf(w3r[0].y, zi.y, fmaf(w3r[0].z, zi.z, w3r[0].w * zi.w)))));
+                prj[1] = pr[p].y + dt * (gm[p] * row_sum16(fmaf(w3r[1].x, zi.x, fmaf(w3r[1].y, zi.y, fmaf(w3r[1].z, zi.z, w3r[1].w * zi.w)))));
+                prj[2] = pr[p].z + dt * (gm[p] * row_sum16(fmaf(w3r[2].x, zi.x, fmaf(w3r[2].y, zi.y, fmaf(w3r[2].z, zi.z, w3r[2].w * zi.w)))));
+                prj[3] = pr[p].w + dt * (gm[p] * row_sum16(fmaf(w3r[3].x, zi.x, fmaf(w3r[3].y, zi.y, fmaf(w3r[3].z, zi.z, w3r[3].w * zi.w)))));
+                pr[p] = make_float4(prj[0], prj[1], prj[2], prj[3]);
             } else {
-                yr = *reinterpret_cast<const float4*>(YR + lrow[p] * TS + 4 * sub);
-                yr.x += dt * dR.x; yr.y += dt * dR.y; yr.z += dt * dR.z; yr.w += dt * dR.w;
-                *reinterpret_cast<float4*>(YR + lrow[p] * TS + 4 * sub) = yr;
+                yr[p].x += dt * dR.x; yr[p].y += dt * dR.y; yr[p].z += dt * dR.z; yr[p].w += dt * dR.w;
             }
             if (solk && valid[p]) {
                 const size_t off = (size_t)(base + lrow[p]) * 64 + 4 * sub;
-                st4g(solk + off, ys); st4g(solk + slab + off, yi); st4g(solk + 2 * slab + off, yr);
+                st4g(solk + off, ys[p]); st4g(solk + slab + off, yi[p]); st4g(solk + 2 * slab + off, yr[p]);
             }
             if (slot >= 0) {
                 float pS, pI, pR;
-                readout64<PRJ>(ys, yi, yr, prj, sub, w3, b3, w2, b2, pS, pI, pR);
+                readout64<PRJ>(ys[p], yi[p], yr[p], prj, sub, w3, b3, w2, b2, pS, pI, pR);
                 if (valid[p] && sub == 0) {
                     const size_t o = (size_t)slot * rows + base + lrow[p];
                     So[o] = pS; Io[o] = pI; Ro[o] = pR;
                 }
             }
         }
-        __syncthreads();                           // Y_I tile complete, T2 free
-        if (blk2) mfma_tile<true>(YI + t * tile_f, Wl, T2, bias_l, w, lane);   // Z_I of the next step
-        else mfma_tile16<true>(YI + t * tile_f, Wl, T2, bias_l, w, lane);
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-            *reinterpret_cast<float4*>(Zn + lrow[p] * TS + 4 * sub) =
-                *reinterpret_cast<const float4*>(T2 + (lrow[p] - t * TILE_ROWS) * TS + 4 * sub);
+        if (k + 1 == sched.n_steps) break;
+        __syncthreads();                           // operand tiles complete; every read of Zc and T2 is done
+        if (blk2) { mfma_tile<true>(YS + t * tile_f, Wl, T2, bias_l, w, lane); mfma_tile<true>(YI + t * tile_f, Wl, Zn + t * tile_f, bias_l, w, lane); }
+        else { mfma_tile16<true>(YS + t * tile_f, Wl, T2, bias_l, w, lane); mfma_tile16<true>(YI + t * tile_f, Wl, Zn + t * tile_f, bias_l, w, lane); }
         __syncthreads();                           // every tile's Z_I' is in place before the next gather
         float* tmp = Zc; Zc = Zn; Zn = tmp;
     }
