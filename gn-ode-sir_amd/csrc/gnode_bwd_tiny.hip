@@ -217,16 +217,16 @@ __global__ __launch_bounds__(512) void k_tiny_bwd64(const int* __restrict__ rowp
             for (int rr = 0; rr < TILE_ROWS; ++rr) sacc += Dt0[rr * TS + tid] + Dt1[rr * TS + tid];
             accb += sacc;
         }
-        __syncthreads();
-        // 5b. g_Y = dpre W over the y tiles, a += g_Y
-        if (blk2) { mfma_tile<false>(Dt0, WlT, Yt0, 0.f, w, lane); mfma_tile<false>(Dt1, WlT, Yt1, 0.f, w, lane); }
-        else { mfma_tile16<false>(Dt0, WlT, Yt0, 0.f, w, lane); mfma_tile16<false>(Dt1, WlT, Yt1, 0.f, w, lane); }
+        // 5b. g_Y = dpre W, written over this tile's rows of the two gather tables (free since the barrier after the
+        //     gathers; no barrier needed against 5a, which only reads Dt / Yt), then a += g_Y
+        if (blk2) { mfma_tile<false>(Dt0, WlT, Qm, 0.f, w, lane); mfma_tile<false>(Dt1, WlT, ZIm, 0.f, w, lane); }
+        else { mfma_tile16<false>(Dt0, WlT, Qm, 0.f, w, lane); mfma_tile16<false>(Dt1, WlT, ZIm, 0.f, w, lane); }
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             if (!valid[p]) continue;
-            const float4 uS = *reinterpret_cast<const float4*>(Yt0 + lr[p] * TS + 4 * sub);
-            const float4 uI = *reinterpret_cast<const float4*>(Yt1 + lr[p] * TS + 4 * sub);
+            const float4 uS = *reinterpret_cast<const float4*>(Qm + lr[p] * TS + 4 * sub);
+            const float4 uI = *reinterpret_cast<const float4*>(ZIm + lr[p] * TS + 4 * sub);
             aS[p].x += uS.x; aS[p].y += uS.y; aS[p].z += uS.z; aS[p].w += uS.w;
             aI[p].x += uI.x; aI[p].y += uI.y; aI[p].z += uI.z; aI[p].w += uI.w;
         }
