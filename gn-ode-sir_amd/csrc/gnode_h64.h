@@ -12,10 +12,13 @@ int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, flo
                      const float* bias, const float* beta, const float* gamma, float dt, const gnode_params* p,
                      float* PR /* [rows][4] projected R state, or null = carry Y_R */, Step64Out out, bool fuse,
                      hipStream_t st);
-int gn_launch_init_pr64(const float* YR, const float* w3, float* PR, long rows, hipStream_t st);
 
 // single-launch integration for graphs whose per-sample state fits one workgroup's LDS (gnode_h64.hip: k_tiny64)
 bool gn_tiny64_ok(int n, int n_steps, int n_out, bool prj);
 int gn_launch_tiny64(const gnode_graph_s* g, long rows, const float* Y0, const float* ZI0, const float* PR0, const float* W,
                      const float* bias, const float* beta, const float* gamma, const float* dt_host, const int* slot_host,
                      int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol, hipStream_t st);
+
+// encoder + beta/gamma + trajectory point 0 + read-out at grid point 0 + projected R + Z_I(y_0) in one launch
+int gn_launch_prologue64(const float* x, const gnode_params* p, float* Y, float* beta, float* gamma, float* sol0, float* ZI,
+                         float* PR, float* S0, float* I0, float* R0, long rows, hipStream_t st);

@@ -470,23 +470,86 @@ int gn_launch_tiny64(const gnode_graph_s* g, long rows, const float* Y0, const f
     return 0;
 }
 
-// PR0[r][k] = w3[k] . Y_R[r]  (once per forward, PRJ mode)
-__global__ __launch_bounds__(256) void k_init_pr64(const float* __restrict__ YR, const float* __restrict__ w3,
-                                                   float* __restrict__ PR, long rows) {
-    const int sub = threadIdx.x & 15;
-    const long r = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const float4 y = r < rows ? ld4g(YR + (size_t)r * 64 + 4 * sub) : zero4();
-    float v[4];
+// --------------------------------------------------------------------------- k_prologue64: everything before the first step
+// encoder (ode_nn_ngraph_sim.py:151-156: relu(Linear(1,H)) on S0, I0, R0 -- a row select, the inputs are 0/1),
+// beta / gamma extraction, trajectory point 0, read-out at grid point 0, projected R (PRJ) and Z_I(y_0) on the
+// matrix cores: one launch instead of four (encoder, read-out, node MLP, R projection).
+__global__ __launch_bounds__(256) void k_prologue64(const float* __restrict__ x, const float* __restrict__ w1,
+                                                    const float* __restrict__ b1, const float* __restrict__ W,
+                                                    const float* __restrict__ bias, const float* __restrict__ w3,
+                                                    const float* __restrict__ b3, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, float* __restrict__ Y,
+                                                    float* __restrict__ beta, float* __restrict__ gamma,
+                                                    float* __restrict__ sol0, float* __restrict__ ZI, float* __restrict__ PR,
+                                                    float* __restrict__ S0, float* __restrict__ I0, float* __restrict__ R0,
+                                                    long rows) {
+    __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
+    __shared__ __attribute__((aligned(16))) float T[TILE_ROWS * TS];
+    __shared__ __attribute__((aligned(16))) float T2[TILE_ROWS * TS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
+    load_W_to_lds<false>(W, Wl);
+    const float bias_l = bias[16 * w + (lane & 15)];
+    const float4 wv = ld4g(w1 + 4 * sub), bv = ld4g(b1 + 4 * sub);
+    const size_t slab = (size_t)rows * 64;
+    const long ntiles = (rows + TILE_ROWS - 1) / TILE_ROWS;
+    const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        long r[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float4 wv = ld4g(w3 + k * 64 + 4 * sub);
-        v[k] = row_sum16(fmaf(wv.x, y.x, fmaf(wv.y, y.y, fmaf(wv.z, y.z, wv.w * y.w))));
+        for (int p = 0; p < 2; ++p) {
+            r[p] = t * TILE_ROWS + lr[p];
+            const bool valid = r[p] < rows;
+            float4 yS = zero4(), yI = zero4(), yR = zero4();
+            if (valid) {
+                const float* xr = x + r[p] * 67;
+                const float s0 = xr[0], i0 = xr[1], r0 = xr[2];
+                auto enc = [&](float v) {
+                    return make_float4(fmaxf(fmaf(wv.x, v, bv.x), 0.f), fmaxf(fmaf(wv.y, v, bv.y), 0.f),
+                                       fmaxf(fmaf(wv.z, v, bv.z), 0.f), fmaxf(fmaf(wv.w, v, bv.w), 0.f));
+                };
+                yS = enc(s0); yI = enc(i0); yR = enc(r0);
+                const size_t off = (size_t)r[p] * 64 + 4 * sub;
+                st4g(Y + off, yS); st4g(Y + slab + off, yI); st4g(Y + 2 * slab + off, yR);
+                if (sub == 0) { beta[r[p]] = xr[3]; gamma[r[p]] = xr[4]; }
+                if (sol0) {
+                    st4g(sol0 + off, yS); st4g(sol0 + slab + off, yI); st4g(sol0 + 2 * slab + off, yR);
+                    const float* bg = xr + 3 + 4 * sub;
+                    st4g(sol0 + 3 * slab + off, make_float4(bg[0], bg[1], bg[2], bg[3]));
+                }
+            }
+            *reinterpret_cast<float4*>(T + lr[p] * TS + 4 * sub) = yI;
+            if (PR) {
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 c = ld4g(w3 + k * 64 + 4 * sub);
+                    v[k] = row_sum16(fmaf(c.x, yR.x, fmaf(c.y, yR.y, fmaf(c.z, yR.z, c.w * yR.w))));
+                }
+                if (valid && sub == 0) st4g(PR + (size_t)r[p] * 4, make_float4(v[0], v[1], v[2], v[3]));
+            }
+            if (S0) {
+                float pS, pI, pR;
+                const float none[4] = {0.f, 0.f, 0.f, 0.f};
+                readout64<false>(yS, yI, yR, none, sub, w3, b3, w2, b2, pS, pI, pR);
+                if (valid && sub == 0) { S0[r[p]] = pS; I0[r[p]] = pI; R0[r[p]] = pR; }
+            }
+        }
+        __syncthreads();
+        mfma_tile<true>(T, Wl, T2, bias_l, w, lane);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (r[p] < rows) st4g(ZI + (size_t)r[p] * 64 + 4 * sub, *reinterpret_cast<const float4*>(T2 + lr[p] * TS + 4 * sub));
+        __syncthreads();
     }
-    if (r < rows && sub == 0) st4g(PR + (size_t)r * 4, make_float4(v[0], v[1], v[2], v[3]));
 }
 
-int gn_launch_init_pr64(const float* YR, const float* w3, float* PR, long rows, hipStream_t st) {
-    hipLaunchKernelGGL(k_init_pr64, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, YR, w3, PR, rows);
+int gn_launch_prologue64(const float* x, const gnode_params* p, float* Y, float* beta, float* gamma, float* sol0, float* ZI,
+                         float* PR, float* S0, float* I0, float* R0, long rows, hipStream_t st) {
+    const long ntiles = (rows + TILE_ROWS - 1) / TILE_ROWS;
+    hipLaunchKernelGGL(k_prologue64, dim3((unsigned)std::min<long>(ntiles, 2048)), dim3(256), 0, st, x, p->linearS1_weight,
+                       p->linearS1_bias, p->odefunc_linear_weight, p->odefunc_linear_bias, p->linear3_weight, p->linear3_bias,
+                       p->linearS2_weight, p->linearS2_bias, Y, beta, gamma, sol0, ZI, PR, S0, I0, R0, rows);
     GN_LAUNCH_CHECK();
     return 0;
 }

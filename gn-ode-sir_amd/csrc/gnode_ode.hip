@@ -604,10 +604,6 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
     float* rk = (float*)(ws + 5 * slab_b + 2 * gn_align((size_t)rows * sizeof(float)) + gn_align((size_t)rows * 4 * sizeof(float)));
 
     const int lpr = lpr_for(H), rpw = 256 / lpr;
-    DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_encode<LPR>, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), 0, st, x,
-                                         p->linearS1_weight, p->linearS1_bias, Y, beta, gamma, sol, (long)rows, H));
-    GN_LAUNCH_CHECK();
-
     int next_out = 0;  // index into the output list
     auto out_slot = [&](int gidx) -> int {   // which output row (or -1) grid point gidx is written to
         if (!out_rows_host) return gidx;
@@ -615,9 +611,6 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         return -1;
     };
     int slot = out_slot(0);
-    if (slot >= 0)
-        if (int e = launch_readout(Y, rows, H, p, S + (size_t)slot * rows, I + (size_t)slot * rows, R + (size_t)slot * rows, st))
-            return e;
 
     // H = 64: fused step kernels (gnode_h64.hip).  GNODE_FUSE=0 keeps Z_I in its own node-MLP launch.
     const bool h64 = (H == 64 && method == 0);
@@ -627,11 +620,22 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
     // inference (no trajectory requested): R only feeds the read-out -> carry its 4-float projection
     static const bool prj_ok = [] { const char* e = getenv("GNODE_PRJ"); return !(e && e[0] == '0'); }();
     float* PR = (h64 && !sol && prj_ok) ? prbuf : nullptr;
-    if ((h64 || (method == 0 && H <= 128)) && n_steps > 0) {
-        if (int e = launch_mlp(Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
-        if (PR) if (int e = gn_launch_init_pr64(Y + 2 * slab, p->linear3_weight, PR, rows, st)) return e;
+    if (h64 && n_steps > 0) {
+        // encoder, beta/gamma, trajectory point 0, read-out at grid point 0, projected R and Z_I(y_0): one launch
+        if (int e = gn_launch_prologue64(x, p, Y, beta, gamma, sol, zi_cur, PR, slot >= 0 ? S + (size_t)slot * rows : nullptr,
+                                         slot >= 0 ? I + (size_t)slot * rows : nullptr,
+                                         slot >= 0 ? R + (size_t)slot * rows : nullptr, rows, st))
+            return e;
+    } else {
+        DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_encode<LPR>, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), 0, st, x,
+                                             p->linearS1_weight, p->linearS1_bias, Y, beta, gamma, sol, (long)rows, H));
+        GN_LAUNCH_CHECK();
+        if (slot >= 0)
+            if (int e = launch_readout(Y, rows, H, p, S + (size_t)slot * rows, I + (size_t)slot * rows, R + (size_t)slot * rows, st))
+                return e;
+        if (method == 0 && H <= 128 && n_steps > 0)
+            if (int e = launch_mlp(Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
     }
-
     if (h64 && fuse_zi && gn_tiny64_ok(g->n, n_steps, out_rows_host ? n_out : G, PR != nullptr)) {
         // tiny graphs: the whole integration in one launch (one workgroup per sample, state in LDS)
         int slots[128];
