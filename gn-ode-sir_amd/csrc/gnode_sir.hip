@@ -33,6 +33,9 @@ __device__ __forceinline__ uint32_t philox_word0(uint32_t c0, uint32_t c1, uint3
 
 // --------------------------------------------------------------------------- production kernel
 // hist: uint32 [2][T][n]: [0] = infection events (t = 0 for seeds), [1] = recovery events.
+#ifndef GN_SIR_UNROLL
+#define GN_SIR_UNROLL 8
+#endif
 template <bool STATE_IN_LDS>
 __global__ __launch_bounds__(1024) void k_sir_philox(const int* __restrict__ src, const int* __restrict__ dst, long nnz,
                                                     int n, const int* __restrict__ seeds, int n_seeds,
@@ -59,15 +62,33 @@ __global__ __launch_bounds__(1024) void k_sir_philox(const int* __restrict__ src
             if (first) atomicAdd(&hinf[v], 1u);
         }
         for (int it = 1; it < T; ++it) {
-            for (long e = threadIdx.x; e < nnz; e += nthr) {
-                const int u = src[e];
-                if (state[u] == ST_I) {
-                    const int v = dst[e];
-                    if (state[v] == ST_S &&
-                        (unsigned long long)philox_word0((uint32_t)e, (uint32_t)it, sim, 0u, k0, k1) < thr_beta)
-                        flag[v] = 1;
+            // GN_SIR_UNROLL source ids in flight per thread: the scan is a chain of (global id load -> LDS state read)
+            // pairs, latency-bound when issued one at a time.  Wiki-vote-size graph, 10 000 sims x T = 20: 38.8 ms at 1,
+            // 25.9 ms at 4, 23.6 ms at 8.  Tried on top, no gain: 16-bit ids (23.4 ms: not bound by the id bytes); four
+            // consecutive edges per lane sharing one Philox block (32.5 ms: a wave then spans ~9 rows instead of ~2 and
+            // runs mostly half-empty).
+#define GN_EDGE(ON, E)                                                                                        \
+                if (ON) {                                                                                     \
+                    const int v = dst[E];                                                                     \
+                    if (state[v] == ST_S &&                                                                   \
+                        (unsigned long long)philox_word0((uint32_t)(E), (uint32_t)it, sim, 0u, k0, k1) < thr_beta) \
+                        flag[v] = 1;                                                                          \
                 }
+            long e = threadIdx.x;
+            for (; e + (long)(GN_SIR_UNROLL - 1) * nthr < nnz; e += (long)GN_SIR_UNROLL * nthr) {
+                int u[GN_SIR_UNROLL]; bool inf[GN_SIR_UNROLL];
+#pragma unroll
+                for (int q = 0; q < GN_SIR_UNROLL; ++q) u[q] = src[e + (long)q * nthr];
+#pragma unroll
+                for (int q = 0; q < GN_SIR_UNROLL; ++q) inf[q] = state[u[q]] == ST_I;
+#pragma unroll
+                for (int q = 0; q < GN_SIR_UNROLL; ++q) GN_EDGE(inf[q], e + (long)q * nthr)
             }
+            for (; e < nnz; e += nthr) {
+                const bool i0 = state[src[e]] == ST_I;
+                GN_EDGE(i0, e)
+            }
+#undef GN_EDGE
             for (int u = threadIdx.x; u < n; u += nthr)
                 if (state[u] == ST_I &&
                     (unsigned long long)philox_word0((uint32_t)u, (uint32_t)it, sim, 1u, k0, k1) < thr_gamma)
