@@ -7,6 +7,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 import pickle
 
 import numpy as np
@@ -18,6 +19,8 @@ from .graph import DeviceGraph
 
 
 def _edge_arrays(G):
+    if hasattr(G, "edge_array"):                      # CsrGraph (restored from the CSR cache file)
+        return G.edge_array
     e = np.asarray(list(G.edges()), dtype=np.int64).reshape(-1, 2)
     return e
 
@@ -126,12 +129,45 @@ def get_sir_t_nodes_torch(x_rk, maxTime, deltaT, count=True):
     return x_rk.index_select(0, idx)
 
 
-def create_graph(n_nodes, graph_label="none"):
+class CsrGraph:
+    """What the path needs from the reference's networkx graph, restored from the CSR cache file: node count,
+    the edge list in `G.edges()` iteration order (sir_torch's table order, ode_nn.py:32-38) and the adjacency."""
+
+    def __init__(self, n, edges):
+        self._n, self.edge_array = int(n), np.ascontiguousarray(edges, dtype=np.int64).reshape(-1, 2)
+
+    def number_of_nodes(self):
+        return self._n
+
+    def number_of_edges(self):
+        return int(self.edge_array.shape[0])
+
+    def edges(self):
+        return [tuple(e) for e in self.edge_array.tolist()]
+
+    def nodes(self):
+        return range(self._n)
+
+
+CACHE_SUFFIX = ".gnode-csr.npz"
+
+
+def create_graph(n_nodes, graph_label="none", cache=False):
     """reference ode_nn.py:394-414: pickled networkx graph -> undirected -> largest
-    connected component -> scipy adjacency.  Returns (G, A, 0)."""
+    connected component -> scipy adjacency.  Returns (G, A, 0).
+
+    cache=True (extension): keep `<graph_label>.gnode-csr.npz` next to the pickle -- node count,
+    edge list in `G.edges()` order, CSR of the adjacency -- and, when it is at least as new as the pickle, ingest
+    from it without unpickling / re-deriving the component and the adjacency (G is then a `CsrGraph`)."""
     import networkx as nx
     if graph_label != "none":
-        with open(graph_label + ".pkl", "rb") as fh:
+        src, cfile = graph_label + ".pkl", graph_label + CACHE_SUFFIX
+        if cache and os.path.exists(cfile) and os.path.getmtime(cfile) >= os.path.getmtime(src):
+            z = np.load(cfile, allow_pickle=False)
+            n = int(z["n"])
+            A = sp.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=(n, n))
+            return CsrGraph(n, z["edges"]), A, 0
+        with open(src, "rb") as fh:
             G = pickle.load(fh)
         G = G.to_undirected()
         largest_cc = max(nx.connected_components(G), key=len)
@@ -139,4 +175,12 @@ def create_graph(n_nodes, graph_label="none"):
     else:
         G = nx.fast_gnp_random_graph(n_nodes, 0.2)
     A = nx.adjacency_matrix(G)
+    if cache and graph_label != "none":
+        # positions, not labels: the reference indexes tensors with node ids and all its graphs are labelled 0..n-1
+        # in node order; anything else is not cacheable in this form
+        nodes = list(G.nodes())
+        if nodes == list(range(len(nodes))):
+            Ac = sp.csr_matrix(A)
+            np.savez(graph_label + CACHE_SUFFIX, n=np.int64(len(nodes)), edges=_edge_arrays(G), data=Ac.data,
+                     indices=Ac.indices, indptr=Ac.indptr)
     return G, A, 0

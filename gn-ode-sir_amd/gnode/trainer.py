@@ -293,7 +293,7 @@ def main_single(argv=None):
     if args.model != "ode_nn":
         raise SystemExit(f"this entry point serves model='ode_nn' only (got {args.model!r})")
     rank, world = sharding.init_from_env()        # torchrun: one process per GPU; plain run: (0, 1)
-    G, A, _ = create_graph(50, args.dataset)
+    G, A, _ = create_graph(50, args.dataset, cache=os.environ.get("GNODE_GRAPH_CACHE", "0") == "1")
     n_nodes = A.shape[0]
     print(n_nodes)
     args.I_indices = [list(map(int, str(i)[1:-1].split(", "))) for i in args.I_indices]      # "[25, 18]" -> [25, 18]
@@ -383,7 +383,7 @@ def main_multi(argv=None):
     names = args.dataset[14:].split("+")
     A_list = []
     for gname in names:                                             # create_graphs, ode_nn_ngraphs.py:154-165
-        _, A, _ = create_graph(0, args.dataset[:14] + gname)
+        _, A, _ = create_graph(0, args.dataset[:14] + gname, cache=os.environ.get("GNODE_GRAPH_CACHE", "0") == "1")
         A_list.append(A)
     print(len(A_list))
     ipg = args.instances_per_graph

@@ -64,3 +64,25 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.GnodeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_create_graph_csr_cache_roundtrip(tmp_path):
+    """graph ingest through the CSR cache file gives the same adjacency, node count and
+    `G.edges()` order (sir_torch's edge-table order) as the pickled networkx graph."""
+    import pickle
+    import networkx as nx
+    from gnode import ode_nn
+    G0 = nx.karate_club_graph()
+    base = str(tmp_path / "karate")
+    with open(base + ".pkl", "wb") as fh:
+        pickle.dump(G0, fh)
+    G1, A1, _ = ode_nn.create_graph(0, base, cache=True)
+    assert os.path.exists(base + ode_nn.CACHE_SUFFIX) and not isinstance(G1, ode_nn.CsrGraph)
+    G2, A2, _ = ode_nn.create_graph(0, base, cache=True)
+    assert isinstance(G2, ode_nn.CsrGraph)
+    assert G2.number_of_nodes() == G1.number_of_nodes() and G2.number_of_edges() == G1.number_of_edges()
+    assert [tuple(e) for e in G1.edges()] == G2.edges()
+    assert (abs(A1 - A2)).nnz == 0
+    assert np.array_equal(ode_nn._edge_arrays(G1), ode_nn._edge_arrays(G2))
+    G3, _, _ = ode_nn.create_graph(0, base)                      # default: the reference's own route
+    assert not isinstance(G3, ode_nn.CsrGraph)
