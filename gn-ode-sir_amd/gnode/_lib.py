@@ -21,6 +21,7 @@ EXPORTS = [
     "gnode_backward_workspace_bytes", "gnode_backward_f32",
     "gnode_sir_workspace_bytes", "gnode_sir_coins_workspace_bytes",
     "gnode_sir_mc_philox", "gnode_sir_mc_coins",
+    "gnode_dmp_workspace_bytes", "gnode_dmp_f32",
     "gnode_profile_enable", "gnode_profile_read",
 ]
 
@@ -65,6 +66,9 @@ def load():
     lib.gnode_forward_workspace_bytes.argtypes = [i64, i32, i32]
     lib.gnode_forward_workspace_bytes.restype = sz
     lib.gnode_forward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp, sz, vp]
+    lib.gnode_dmp_workspace_bytes.argtypes = [vp]
+    lib.gnode_dmp_workspace_bytes.restype = sz
+    lib.gnode_dmp_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
     lib.gnode_backward_workspace_bytes.argtypes = [i64, i32]
     lib.gnode_backward_workspace_bytes.restype = sz
     lib.gnode_backward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, vp, i32, vp, vp, vp, vp,

@@ -139,6 +139,22 @@ int gnode_sir_mc_coins(const int32_t* table_src, const int32_t* table_dst, int64
                        int32_t T, const double* coins, int64_t n_coins, uint32_t* counts,
                        int64_t* coins_used_host, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- DMP baseline (reference dmp.py:74-170, `DMP_SIR.run`) ----
+ * Dynamic message passing marginals of the SIR process on an UNDIRECTED graph
+ * (symmetric sparsity pattern; GNODE_ERR_ARG otherwise).  Directed edges are the
+ * CSR positions of the handle in row-major order (what `sp.coo_matrix(weight_adj)`
+ * yields, dmp.py:67-72).
+ *   weights   device fp32 [nnz]   transmission probability of each directed edge
+ *                                 (the reference passes A*beta, dmp.py:349)
+ *   gamma     device fp32 [n]     recovery probability of each node (dmp.py:349)
+ *   out       device fp32 [maxTime, n, 3] = (Ps, Pi, Pr), row 0 = initial state
+ *                                 (`DMP_SIR.output()`, dmp.py:159-162)
+ * Not on the `model='ode_nn'` path: a comparison column of the paper. */
+size_t gnode_dmp_workspace_bytes(gnode_graph_t g);
+int gnode_dmp_f32(gnode_graph_t g, const float* weights, const float* gamma, const int32_t* seeds_host,
+                  int32_t n_seeds, int32_t maxTime, float* out, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
 /* ---- instrumentation -------------------------------------------------------
  * While enabled, every launch of the two step kernels (0: gather + SIR update +
  * read-out, 1: node MLP) is bracketed by HIP events on the launch stream;

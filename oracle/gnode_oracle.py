@@ -587,3 +587,63 @@ def chung_lu_graph(n, m, exponent=0.8, seed=0):
     e = np.stack([have // n, have % n], 1)
     rp, ci = csr_from_edges(n, e)
     return rp, ci, e
+
+
+# --------------------------------------------------------------------------- DMP baseline
+def dmp_reverse_index(rowptr, col):
+    """rev[e] = CSR position of the reverse of directed edge e = (row -> col[e]), or nnz when the reverse is absent
+    (reference dmp.py:35-50 `cave_index`, there via a networkx DiGraph lookup)."""
+    n, nnz = len(rowptr) - 1, len(col)
+    src = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+    pos = {(int(s), int(t)): e for e, (s, t) in enumerate(zip(src, col))}
+    return np.array([pos.get((int(t), int(s)), nnz) for s, t in zip(src, col)], dtype=np.int64)
+
+
+def dmp_sir(rowptr, col, weights, gamma, seeds, maxTime):
+    """Dynamic message passing for SIR, reference dmp.py:74-170 (`DMP_SIR.run`), restated in float32 numpy with the
+    reference's operation order.  Directed edges are the CSR positions in row-major order (what
+    `sp.coo_matrix(weight_adj)` yields, dmp.py:67-72): src = row, tar = col, `weights` [nnz], `gamma` [n].
+    `scatter(..., reduce='mul')` (torch_scatter, ABSENT here: parity unpinned) multiplies in ascending edge order.
+    Returns float32 [maxTime, n, 3] = (Ps, Pi, Pr) per step, step 0 = the initial condition."""
+    f = np.float32
+    n, E = len(rowptr) - 1, len(col)
+    src = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+    tar = np.asarray(col, dtype=np.int64)
+    cave = dmp_reverse_index(rowptr, col)
+    w = np.asarray(weights, dtype=f)
+    g_node = np.asarray(gamma, dtype=f)
+    g_edge = g_node[src]
+
+    def scatter_mul(vals, index, size):
+        out = np.ones(size, dtype=f)
+        for e in range(len(vals)):                      # ascending edge order, one float32 product at a time
+            out[index[e]] = f(out[index[e]] * vals[e])
+        return out
+
+    def mulmul(theta):
+        P = scatter_mul(theta, tar, n)[src]
+        cav = scatter_mul(theta, cave, E + 1)[:E]
+        return (P / cav).astype(f)
+
+    seedv = np.zeros(n, dtype=f); seedv[list(seeds)] = 1
+    Ps0, Pi0, Pr0 = (f(1) - seedv).astype(f), seedv.copy(), np.zeros(n, dtype=f)
+    Ps_i0 = Ps0[src]
+    Phi = (f(1) - Ps_i0).astype(f)
+    theta = ((np.ones(E, dtype=f) - w * Phi).astype(f) + f(1e-10)).astype(f)          # dmp.py:117
+    Ps_prev = Ps_i0
+    Ps_e = (Ps_i0 * mulmul(theta)).astype(f)
+    Phi = ((f(1) - w) * (f(1) - g_edge) * Phi - (Ps_e - Ps_prev)).astype(f)
+    Ps_t = (Ps0 * scatter_mul(theta, tar, n)).astype(f)
+    Pr_t = (Pr0 + g_node * Pi0).astype(f)
+    Pi_t = (f(1) - Ps_t - Pr_t).astype(f)
+    out = [np.stack([Ps0, Pi0, Pr0], 1), np.stack([Ps_t, Pi_t, Pr_t], 1)]
+    for _ in range(maxTime - 2):
+        theta = (theta - w * Phi).astype(f)
+        new_Ps = (Ps_i0 * mulmul(theta)).astype(f)
+        Ps_prev, Ps_e = Ps_e, new_Ps
+        Phi = ((f(1) - w) * (f(1) - g_edge) * Phi - (Ps_e - Ps_prev)).astype(f)
+        Ps_t = (Ps0 * scatter_mul(theta, tar, n)).astype(f)
+        Pr_t = (Pr_t + g_node * Pi_t).astype(f)
+        Pi_t = (f(1) - Ps_t - Pr_t).astype(f)
+        out.append(np.stack([Ps_t, Pi_t, Pr_t], 1))
+    return np.stack(out, 0).astype(f)

@@ -556,3 +556,40 @@ def test_randomized_configurations(dev):
             assert _rel(got.cpu().numpy(), w[idx, :, 0]) <= RTOL, tag
         if want_sol:
             assert _rel(sol.cpu().numpy(), sol_o) <= RTOL, tag
+
+
+@pytest.mark.parametrize("name", ["karate", "er120", "loops40"])
+def test_dmp_baseline_golden(name, dev):
+    """DMP comparison column (reference dmp.py:74-170) through the reference's class surface,
+    against vectors the reference class produced.  fp32 1e-5 relative (the GPU's product over a node's
+    in-edges runs in the same ascending order; differences come from fused multiply-adds being off / on nowhere)."""
+    import scipy.sparse as sp
+    from gnode.dmp import DMP_SIR
+    d = np.load(os.path.join(GOLD, f"dmp_{name}.npz"))
+    n = len(d["rowptr"]) - 1
+    W = sp.csr_matrix((d["weights"], d["col"], d["rowptr"]), shape=(n, n))
+    m = DMP_SIR(W, d["gamma"])
+    out = m.run(d["seeds"].tolist(), int(d["maxTime"]))
+    assert tuple(out.shape) == d["out"].shape
+    assert _rel(out.cpu().numpy(), d["out"]) <= RTOL
+    tot = out.sum(-1).cpu().numpy()
+    assert np.allclose(tot, 1.0, atol=1e-5)                  # Ps + Pi + Pr = 1 by construction (dmp.py:129)
+
+
+def test_dmp_vs_oracle_larger_and_errors(dev):
+    import scipy.sparse as sp
+    import gnode_oracle as O
+    from gnode.dmp import DMP_SIR
+    from gnode._lib import GnodeError
+    rp, ci, _ = O.er_graph(3000, 20000, seed=4)
+    rng = np.random.default_rng(0)
+    w = rng.uniform(0.05, 0.4, size=ci.shape[0]).astype(np.float32)      # per-edge weights, not symmetric in value
+    gam = rng.uniform(0.1, 0.5, size=3000).astype(np.float32)
+    W = sp.csr_matrix((w, ci, rp), shape=(3000, 3000))
+    out = DMP_SIR(W, gam).run([7, 100, 2999], 25).cpu().numpy()
+    want = O.dmp_sir(rp, ci, w, gam, [7, 100, 2999], 25)
+    assert _rel(out, want) <= RTOL
+    # a directed (non-symmetric) pattern is refused, loudly
+    D = sp.csr_matrix((np.ones(2, np.float32), np.array([1, 2], np.int32), np.array([0, 1, 2, 2], np.int32)), shape=(3, 3))
+    with pytest.raises(GnodeError):
+        DMP_SIR(D, [0.1, 0.1, 0.1]).run([0], 5)

@@ -123,3 +123,13 @@ def test_er_graph_contract():
     for r in range(500):
         seg = ci[rp[r]:rp[r + 1]]
         assert np.all(np.diff(seg) > 0)
+
+
+@pytest.mark.parametrize("name", ["karate", "er120", "loops40"])
+def test_dmp_oracle_matches_reference_vectors(name):
+    """DMP baseline: the numpy restatement against vectors the reference class produced
+    (tests/golden/make_golden_dmp.py; torch_scatter's scatter-mul itself is parity unpinned)."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", f"dmp_{name}.npz"))
+    got = O.dmp_sir(d["rowptr"], d["col"], d["weights"], d["gamma"], d["seeds"].tolist(), int(d["maxTime"]))
+    assert got.shape == d["out"].shape
+    assert np.array_equal(got, d["out"])                     # same float32 operation order: bit-exact on the CPU
