@@ -22,6 +22,7 @@ EXPORTS = [
     "gnode_sir_workspace_bytes", "gnode_sir_coins_workspace_bytes",
     "gnode_sir_mc_philox", "gnode_sir_mc_coins",
     "gnode_dmp_workspace_bytes", "gnode_dmp_f32",
+    "gnode_meanfield_workspace_bytes", "gnode_meanfield_f64",
     "gnode_profile_enable", "gnode_profile_read",
 ]
 
@@ -66,6 +67,10 @@ def load():
     lib.gnode_forward_workspace_bytes.argtypes = [i64, i32, i32]
     lib.gnode_forward_workspace_bytes.restype = sz
     lib.gnode_forward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp, sz, vp]
+    lib.gnode_meanfield_workspace_bytes.argtypes = [vp]
+    lib.gnode_meanfield_workspace_bytes.restype = sz
+    lib.gnode_meanfield_f64.argtypes = [vp, vp, i32, C.c_double, vp, vp, i32, C.c_double, C.c_double, vp, vp, vp,
+                                        C.POINTER(C.c_int64), vp, sz, vp]
     lib.gnode_dmp_workspace_bytes.argtypes = [vp]
     lib.gnode_dmp_workspace_bytes.restype = sz
     lib.gnode_dmp_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]

@@ -3,6 +3,7 @@
     sir_torch(G, seed_set, beta, gamma, sims=10000, T=20)        reference :30-88
     get_sir_t_nodes_torch(x_rk, maxTime, deltaT, count=True)     reference :249-261
     create_graph(n_nodes, graph_label='none')                    reference :394-414
+    sir(x, y, A, beta, gamma), runge_kutta_order4(sir, A, ...)   reference :214-233 (mean-field comparison column)
 """
 from __future__ import annotations
 
@@ -127,6 +128,41 @@ def get_sir_t_nodes_torch(x_rk, maxTime, deltaT, count=True):
     if count:
         return torch.sum(x_rk, axis=1).index_select(0, idx)
     return x_rk.index_select(0, idx)
+
+
+def sir(x, y, A, beta, gamma):
+    """Mean-field RHS, reference ode_nn.py:214-220 (numpy; kept for callers that pass it to `runge_kutta_order4`)."""
+    n = np.shape(A)[0]
+    S, I = x[:n], x[n:2 * n]
+    AI = np.asarray(A @ I).reshape(-1)
+    dS = -beta * AI * S
+    return np.hstack([dS, -dS - gamma * I, gamma * I])
+
+
+def runge_kutta_order4(sir, A, n_nodes, indices, beta_factor, gamma_factor, deltaT=1, maxTime=70, rtol=1e-10, atol=1e-12):
+    """Mean-field baseline, reference ode_nn.py:222-233 (despite its name the reference runs scipy's LSODA):
+    returns (I_sampled_t, S_sampled_t, R_sampled_t), float64 [maxTime, n] at the times int(i/deltaT)*deltaT.
+    `sir` (the RHS callable) is accepted for signature compatibility; the integration runs in libgnode_hip.so
+    (adaptive Dormand-Prince 5(4), sparse A I) -- SURVEY 8f rank 4, not on the `ode_nn` path."""
+    lib = _lib.load()
+    Ac = sp.csr_matrix(A)
+    Ac.sort_indices()
+    g = DeviceGraph(Ac.indptr.astype(np.int32), Ac.indices.astype(np.int32))
+    n = Ac.shape[0]
+    grid = np.arange(0, maxTime, deltaT)
+    t_out = np.ascontiguousarray([grid[int(i / deltaT)] for i in range(int(maxTime))], dtype=np.float64)
+    seeds = np.ascontiguousarray(list(indices), dtype=np.int32)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gam = torch.full((n,), float(gamma_factor), dtype=torch.float64, device=dev)
+    out = torch.empty((3, len(t_out), n), dtype=torch.float64, device=dev)
+    ws = torch.empty(lib.gnode_meanfield_workspace_bytes(g.handle), dtype=torch.uint8, device=dev)
+    steps = C.c_int64(0)
+    _lib.check(lib.gnode_meanfield_f64(g.handle, _lib.host_ptr(seeds), int(seeds.shape[0]), float(beta_factor), _lib.ptr(gam),
+                                       _lib.host_ptr(t_out), int(len(t_out)), float(rtol), float(atol), _lib.ptr(out[0]),
+                                       _lib.ptr(out[1]), _lib.ptr(out[2]), C.byref(steps), _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr()))
+    o = out.cpu().numpy()
+    return o[0], o[1], o[2]
 
 
 class CsrGraph:

@@ -155,6 +155,22 @@ int gnode_dmp_f32(gnode_graph_t g, const float* weights, const float* gamma, con
                   int32_t n_seeds, int32_t maxTime, float* out, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* ---- mean-field baseline (reference ode_nn.py:214-233) ----
+ * `runge_kutta_order4(sir, A, ...)`: dS = -beta (A I) S, dI = beta (A I) S - gamma I,
+ * dR = gamma I from S = 1 - seeds, I = seeds, R = 0, float64, sampled at the given
+ * times (the reference samples scipy LSODA's solution at int(i/deltaT)*deltaT,
+ * ode_nn.py:229-232,235-246).  A = the handle's unweighted adjacency (entries 1,
+ * a self-loop counts once).  Adaptive Dormand-Prince 5(4) with steps clipped to the
+ * output times; rtol/atol are per component.  t_out_host: host fp64 [n_out],
+ * ascending, t_out[0] = 0.  gamma: device fp64 [n].  outI/outS/outR: device fp64
+ * [n_out, n] (the reference returns I, S, R in that order).  *steps_host (may be
+ * NULL) receives the number of attempted steps.  Synchronises `stream`.
+ * Not on the `model='ode_nn'` path: a comparison column of the paper. */
+size_t gnode_meanfield_workspace_bytes(gnode_graph_t g);
+int gnode_meanfield_f64(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta, const double* gamma,
+                        const double* t_out_host, int32_t n_out, double rtol, double atol, double* outI, double* outS,
+                        double* outR, int64_t* steps_host, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- instrumentation -------------------------------------------------------
  * While enabled, every launch of the two step kernels (0: gather + SIR update +
  * read-out, 1: node MLP) is bracketed by HIP events on the launch stream;

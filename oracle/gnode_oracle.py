@@ -647,3 +647,26 @@ def dmp_sir(rowptr, col, weights, gamma, seeds, maxTime):
         Pi_t = (f(1) - Ps_t - Pr_t).astype(f)
         out.append(np.stack([Ps_t, Pi_t, Pr_t], 1))
     return np.stack(out, 0).astype(f)
+
+
+# --------------------------------------------------------------------------- mean-field baseline
+def meanfield_rk(rowptr, col, seeds, beta, gamma, deltaT, maxTime):
+    """`runge_kutta_order4` of the reference (ode_nn.py:222-233) with its RHS `sir` (:214-220): scipy's LSODA (default
+    tolerances) on t = arange(0, maxTime, deltaT), rows int(i/deltaT) kept.  The only restatement is the sparse A I
+    instead of the dense np.dot.  Returns (I, S, R), float64 [maxTime, n]."""
+    import scipy.sparse as sp
+    from scipy.integrate import odeint
+    n = len(rowptr) - 1
+    A = sp.csr_matrix((np.ones(len(col)), np.asarray(col), np.asarray(rowptr)), shape=(n, n))
+    gam = gamma * np.ones(n)
+
+    def rhs(x, t):
+        S, I = x[:n], x[n:2 * n]
+        AI = A @ I
+        dS = -beta * AI * S
+        return np.hstack([dS, -dS - gam * I, gam * I])
+
+    y0 = np.zeros(3 * n); y0[n + np.asarray(list(seeds), dtype=np.int64)] = 1.0; y0[:n] = 1.0 - y0[n:2 * n]
+    sol = odeint(rhs, y0, np.arange(0, maxTime, deltaT))
+    rows = [int(i / deltaT) for i in range(int(maxTime))]
+    return sol[rows, n:2 * n], sol[rows, :n], sol[rows, 2 * n:]

@@ -593,3 +593,34 @@ def test_dmp_vs_oracle_larger_and_errors(dev):
     D = sp.csr_matrix((np.ones(2, np.float32), np.array([1, 2], np.int32), np.array([0, 1, 2, 2], np.int32)), shape=(3, 3))
     with pytest.raises(GnodeError):
         DMP_SIR(D, [0.1, 0.1, 0.1]).run([0], 5)
+
+
+@pytest.mark.parametrize("name", ["karate", "er150"])
+def test_meanfield_baseline_golden(name, dev):
+    """Mean-field comparison column through the reference's function surface against vectors
+    the reference's own `runge_kutta_order4` produced with scipy's LSODA.  The device integrator is a different
+    (explicit, adaptive, much tighter) method: agreement is bounded by LSODA's own tolerance (1.5e-8 per step) --
+    1e-6 absolute on probabilities in [0, 1]."""
+    import scipy.sparse as sp
+    from gnode import ode_nn
+    d = np.load(os.path.join(GOLD, f"meanfield_{name}.npz"))
+    n = len(d["rowptr"]) - 1
+    A = sp.csr_matrix((np.ones(len(d["col"])), d["col"], d["rowptr"]), shape=(n, n))
+    I, S, R = ode_nn.runge_kutta_order4(ode_nn.sir, A, n, d["seeds"].tolist(), float(d["beta"]), float(d["gamma"]),
+                                        float(d["deltaT"]), int(d["maxTime"]))
+    for got, want in ((I, d["I"]), (S, d["S"]), (R, d["R"])):
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) <= 1e-6
+    assert np.max(np.abs(I + S + R - 1.0)) <= 1e-9            # conserved by the RHS; RK methods keep linear invariants
+
+
+def test_meanfield_vs_oracle_larger(dev):
+    import scipy.sparse as sp
+    import gnode_oracle as O
+    from gnode import ode_nn
+    rp, ci, _ = O.er_graph(2000, 12000, seed=9)
+    A = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(2000, 2000))
+    I, S, R = ode_nn.runge_kutta_order4(ode_nn.sir, A, 2000, [1, 500], 0.03, 0.2, 0.5, 12)
+    Io, So, Ro = O.meanfield_rk(rp, ci, [1, 500], 0.03, 0.2, 0.5, 12)
+    for got, want in ((I, Io), (S, So), (R, Ro)):
+        assert np.max(np.abs(got - want)) <= 1e-6

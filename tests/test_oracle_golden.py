@@ -133,3 +133,16 @@ def test_dmp_oracle_matches_reference_vectors(name):
     got = O.dmp_sir(d["rowptr"], d["col"], d["weights"], d["gamma"], d["seeds"].tolist(), int(d["maxTime"]))
     assert got.shape == d["out"].shape
     assert np.array_equal(got, d["out"])                     # same float32 operation order: bit-exact on the CPU
+
+
+@pytest.mark.parametrize("name", ["karate", "er150"])
+def test_meanfield_oracle_matches_reference_vectors(name):
+    """Mean-field baseline: scipy LSODA on the sparse matrix vs the reference's
+    `runge_kutta_order4` on the dense one (tests/golden/make_golden_meanfield.py).  Same integrator, same
+    tolerances; only the summation order inside A I differs."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", f"meanfield_{name}.npz"))
+    I, S, R = O.meanfield_rk(d["rowptr"], d["col"], d["seeds"].tolist(), float(d["beta"]), float(d["gamma"]),
+                             float(d["deltaT"]), int(d["maxTime"]))
+    for got, want in ((I, d["I"]), (S, d["S"]), (R, d["R"])):
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) <= 1e-9
