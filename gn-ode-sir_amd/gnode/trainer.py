@@ -332,7 +332,12 @@ def main_single(argv=None):
     if rank != 0:
         return 0
     if not args.out_of_dist:
-        save_trial_to_csv(args, best_epoch, best_loss, test_loss, 0, t_test, 0)
+        # the reference leaves the mean-field comparison switched off (ode_nn_ngraph_sim.py:473-474: zeros in the CSV);
+        # GNODE_RK_BASELINE=1 fills the two columns with `runge_kutta_baseline` (:298-317) on the test samples
+        loss_baseline, rk_time = 0, 0
+        if os.environ.get("GNODE_RK_BASELINE", "0") == "1":
+            loss_baseline, rk_time = runge_kutta_baseline(A, args, te, ys)
+        save_trial_to_csv(args, best_epoch, best_loss, test_loss, loss_baseline, t_test, rk_time)
     else:
         rel = os.path.relpath(args.dataset, "./real_graphs/")
         csv_trials(args.path_to_save + "/Out-of-dist-gamma-" + rel, [str(i) for i in ood["test"]], test_all)
@@ -341,6 +346,23 @@ def main_single(argv=None):
                    [args.trial, args.model, args.lr, args.epochs, args.deltaT, args.maxTime, args.hidden, best_epoch, best_loss,
                     test_loss, t_test])
     return 0
+
+
+def runge_kutta_baseline(A, args, test_ids, ys):
+    """reference ode_nn_ngraph_sim.py:298-317: mean of the three per-compartment MAEs of the mean-field solution
+    against the Monte-Carlo labels, averaged over the test samples; returns (loss, seconds)."""
+    from .ode_nn import runge_kutta_order4, sir
+    t0, losses = time.time(), []
+    for i in test_ids:
+        I_t, S_t, R_t = runge_kutta_order4(sir, A, A.shape[0], args.I_indices[i], args.beta[i], args.gamma[i], args.deltaT,
+                                           args.maxTime)
+        y = ys[i].cpu().numpy()                                   # [n, T, 3]
+        losses.append((np.abs(S_t - y[:, :, 0].T).mean() + np.abs(I_t - y[:, :, 1].T).mean() +
+                       np.abs(R_t - y[:, :, 2].T).mean()) / 3)
+    dt = time.time() - t0
+    print("Runge-kutta baseline Loss: {:.5f}".format(float(np.mean(losses))))
+    print("Time inference baseline: {:.5f}".format(dt))
+    return float(np.mean(losses)), dt
 
 
 # --------------------------------------------------------------------------- multi-graph entry (ode_nn_ngraphs.py:291-415)

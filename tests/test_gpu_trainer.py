@@ -50,10 +50,14 @@ def test_single_graph_entry_point(tmp_path, monkeypatch, dev):
     df = pd.read_csv(d + "/Metrics-trials-toy")
     assert list(df.columns)[:4] == ["trial", "model", "lr", "epochs"] and len(df) == 1 and df["model"][0] == "ode_nn"
     assert np.isfinite(df["test_loss"][0]) and df["test_loss"][0] < 0.5
-    # second trial appends a row and reuses the label cache
+    # second trial appends a row and reuses the label cache; with the mean-field comparison switched on
+    # (the reference's `runge_kutta_baseline`, ode_nn_ngraph_sim.py:298-317, commented out there at :473)
     argv[argv.index("--trial") + 1] = "1"
+    monkeypatch.setenv("GNODE_RK_BASELINE", "1")
     assert main_single(argv) == 0
-    assert len(pd.read_csv(d + "/Metrics-trials-toy")) == 2
+    monkeypatch.delenv("GNODE_RK_BASELINE")
+    df = pd.read_csv(d + "/Metrics-trials-toy")
+    assert len(df) == 2 and df["loss_baseline"][0] == 0 and 0 < df["loss_baseline"][1] < 0.5 and df["rk_time"][1] > 0
     # out-of-distribution split
     pickle.dump({"train": [0, 1, 2, 3, 4], "val": [5, 6], "test": [7, 8, 9]}, open(d + "/out-of-dist-gamma.pkl", "wb"))
     assert main_single(argv + ["--out_of_dist"]) == 0
