@@ -365,6 +365,45 @@ def runge_kutta_baseline(A, args, test_ids, ys):
     return float(np.mean(losses)), dt
 
 
+# --------------------------------------------------------------------------- DMP comparison entry (dmp.py:212-375)
+def main_dmp(argv=None):
+    """What monitorer-sim.py spawns for model='dmp' (monitorer-sim.py:30-31): same argv and label / initial-* files
+    as the single-graph script; runs `DMP_SIR(A*beta, [gamma]*n).run(seeds, maxTime)` on every test sample and
+    prints the element-weighted L1 against the Monte-Carlo labels (dmp.py:345-364; the reference saves nothing)."""
+    from .dmp import DMP_SIR
+    args = parser_single().parse_args(argv)
+    G, A, _ = create_graph(50, args.dataset, cache=os.environ.get("GNODE_GRAPH_CACHE", "0") == "1")
+    n_nodes = A.shape[0]
+    print(n_nodes)
+    args.I_indices = [list(map(int, str(i)[1:-1].split(", "))) for i in args.I_indices]
+    if not os.path.exists(args.path_to_save + "/initial-seed.pkl"):
+        pickle.dump(args.I_indices, open(args.path_to_save + "/initial-seed.pkl", "wb"))
+        pickle.dump(args.beta, open(args.path_to_save + "/initial-beta.pkl", "wb"))
+        pickle.dump(args.gamma, open(args.path_to_save + "/initial-gamma.pkl", "wb"))
+    ys = []
+    for i, seeds in enumerate(args.I_indices):
+        S, I, R = load_SIR_labels(args.dataset, args.path_to_save, G, seeds, args.beta[i], args.gamma[i], args.sim, args.maxTime)
+        ys.append(np.stack([np.asarray(S), np.asarray(I), np.asarray(R)], -1))       # [T, n, 3]
+    ood = pickle.load(open(args.path_to_save + "/out-of-dist-gamma.pkl", "rb")) if args.out_of_dist else None
+    _, _, te = split_indices(len(ys), args.train_val_test_ratio, ood)
+    import scipy.sparse as sp
+    A1 = sp.csr_matrix(A).astype(np.float64)
+    A1.data[:] = 1.0                                              # the reference multiplies the 0/1 adjacency by beta (:349)
+    t0, loss_all, items = time.time(), 0.0, 0
+    for i in te:
+        print("dmp")
+        out = DMP_SIR(A1 * args.beta[i], [args.gamma[i]] * n_nodes).run(args.I_indices[i], args.maxTime).cpu().numpy()
+        loss = float(np.abs(out[1:].astype(np.float64) - ys[i][1:]).mean())
+        cnt = 3 * n_nodes * (args.maxTime - 1)
+        loss_all += loss * cnt
+        items += cnt
+        print(loss)
+    test_loss = loss_all / max(items, 1)
+    print("DMP baseline Loss: {:.5f}".format(test_loss))
+    print("Time inference baseline: {:.5f}".format(time.time() - t0))
+    return 0
+
+
 # --------------------------------------------------------------------------- multi-graph entry (ode_nn_ngraphs.py:291-415)
 def parser_multi():
     p = argparse.ArgumentParser(description="Neural ODE")

@@ -58,6 +58,14 @@ def test_single_graph_entry_point(tmp_path, monkeypatch, dev):
     monkeypatch.delenv("GNODE_RK_BASELINE")
     df = pd.read_csv(d + "/Metrics-trials-toy")
     assert len(df) == 2 and df["loss_baseline"][0] == 0 and 0 < df["loss_baseline"][1] < 0.5 and df["rk_time"][1] > 0
+    # the DMP comparison entry point on the same experiment directory (monitorer-sim.py:30-31 -> dmp.py)
+    from gnode.trainer import main_dmp
+    import io, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert main_dmp(argv[:-1] + ["dmp"]) == 0
+    line = [l for l in buf.getvalue().splitlines() if l.startswith("DMP baseline Loss")]
+    assert len(line) == 1 and 0 < float(line[0].split(":")[1]) < 0.5
     # out-of-distribution split
     pickle.dump({"train": [0, 1, 2, 3, 4], "val": [5, 6], "test": [7, 8, 9]}, open(d + "/out-of-dist-gamma.pkl", "wb"))
     assert main_single(argv + ["--out_of_dist"]) == 0
