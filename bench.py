@@ -193,7 +193,20 @@ def main():
         torch.set_num_threads(cores)
         cs = min(args.cpu_steps, n_steps)
         _, _, _, secs, done = O.torch_port_forward(x_host[:1], P, rp, ci, args.maxTime, args.deltaT, n_steps=cs, threads=cores)
+        # second CPU figure: the optimised C + OpenMP restatement of the same path (a pull CSR gather
+        # instead of the reference's repeat / gather / scatter_add_ sequence), same sample, same cores
+        c_port = None
+        try:
+            import oracle_c as OC
+            import time as _t
+            t0 = _t.perf_counter()
+            OC.forward_euler(rp, ci, n, x_host[:1], P, np.asarray(O.time_grid(args.maxTime, args.deltaT)[1:cs + 1] -
+                                                                O.time_grid(args.maxTime, args.deltaT)[:cs], np.float32))
+            c_port = n * cs / (_t.perf_counter() - t0)
+        except Exception as exc:                                  # the C checker is optional for the bench line
+            c_port = f"unavailable: {type(exc).__name__}"
         result["cpu_baseline"] = {"value": n * done / secs, "unit": "node-timesteps/s", "cores": cores, "kind": "port",
+                                  "c_openmp_port_value": c_port,
                                   "sample": f"1 sample x {done} Euler steps of the same graph (reference op sequence "
                                             f"in PyTorch-CPU: repeat-index + gather + scatter_add_), {secs:.1f} s"}
     if rank == 0:
