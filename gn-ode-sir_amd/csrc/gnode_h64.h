@@ -22,3 +22,6 @@ int gn_launch_tiny64(const gnode_graph_s* g, long rows, const float* Y0, const f
 // encoder + beta/gamma + trajectory point 0 + read-out at grid point 0 + projected R + Z_I(y_0) in one launch
 int gn_launch_prologue64(const float* x, const gnode_params* p, float* Y, float* beta, float* gamma, float* sol0, float* ZI,
                          float* PR, float* S0, float* I0, float* R0, long rows, hipStream_t st);
+
+// H = 128 node MLP on the matrix cores (gnode_h128.hip)
+int gn_launch_mlp128(const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st);

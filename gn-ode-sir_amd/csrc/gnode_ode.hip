@@ -408,6 +408,8 @@ static int launch_mlp(const float* X, const float* W, const float* b, float* Z, 
     const bool sampled = prof_begin(1, st);
     if (H == 64) {
         if (int e = gn_launch_mlp64(X, W, b, Z, nrows, st)) return e;
+    } else if (H == 128) {
+        if (int e = gn_launch_mlp128(X, W, b, Z, nrows, st)) return e;       // matrix cores (gnode_h128.hip)
     } else {
         GN_CHECK_ARG(H <= 128, "generic node-MLP path supports H <= 128 (got %d)", H);
         const int lpr = lpr_for(H);
@@ -633,7 +635,7 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         if (slot >= 0)
             if (int e = launch_readout(Y, rows, H, p, S + (size_t)slot * rows, I + (size_t)slot * rows, R + (size_t)slot * rows, st))
                 return e;
-        if (method == 0 && H <= 128 && n_steps > 0)
+        if (method == 0 && H < 128 && n_steps > 0)
             if (int e = launch_mlp(Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
     }
     if (h64 && fuse_zi && gn_tiny64_ok(g->n, n_steps, out_rows_host ? n_out : G, PR != nullptr)) {
@@ -670,8 +672,9 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
                 if (int e = launch_mlp((sol_next ? sol_next : Y) + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur,
                                        rows, H, st))
                     return e;
-        } else if (method == 0 && H <= 128) {
-            // generic H: one fused launch per step (gather + both node MLPs as lane-group mat-vecs)
+        } else if (method == 0 && H < 128) {
+            // generic H: one fused launch per step (gather + both node MLPs as lane-group mat-vecs); H = 128 takes the
+            // two-launch branch below, whose node MLP runs on the matrix cores (a VALU mat-vec is 12x off the bound there)
             StepOut out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
                            slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
             const float* AIhub = nullptr;
