@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 n, m, B = 75000, 500000, 8
 rp, ci, _ = O.er_graph(n, m, seed=0)
 g = DeviceGraph(rp, ci)
-for H in (8, 16, 32, 64, 128):
+for H in ([int(v) for v in sys.argv[1:]] or (8, 16, 32, 64, 128)):
     P = {k: torch.from_numpy(v).to(dev) for k, v in O.init_params(H, seed=0).items()}
     x = torch.from_numpy(O.make_samples(n, B, H, seed=1)).to(dev).reshape(B * n, 3 + H)
     dts = ops.step_sizes(ops.time_grid(30, 0.5))
