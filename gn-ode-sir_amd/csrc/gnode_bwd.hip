@@ -1078,6 +1078,9 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
             BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_bwd_gather<LPR>, ggrid, dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, H,
                                                  a, Z, q, beta, gamma, dpre, g->hubidx, AIhub, GQhub, g->n_hub));
             GN_LAUNCH_CHECK();
+            if (H == 128) {
+                if (int e = gn_launch_bwd_mlp128(dpre, yi, p->odefunc_linear_weight, dt, a, rows, part, &slots_used, st)) return e;
+            } else
             BWD_DISPATCH(lpr, {
                 static bool attr_set = false;      // once per instantiation, never inside a stream capture
                 if (mlp_lds > 64 * 1024 && !attr_set) {
