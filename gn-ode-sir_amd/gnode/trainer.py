@@ -223,32 +223,35 @@ class Runner:
 
     def train_epoch(self, xs, ys, batch_size, epoch):
         self.model.train()
-        tot, items, t_fwd = 0.0, 0, 0.0
+        items, t_fwd = 0, 0.0
+        # the epoch's loss sum stays on the device: one host sync per EPOCH, not one per optimiser step, so the host
+        # runs ahead and the launch-bound small configurations are not throttled by a D2H read-back every step
+        tot_t = torch.zeros((), dtype=torch.float64, device=self.device)
         T = ys[0].shape[1] if ys else 0
         for sel in self.batches(len(xs), batch_size, True, epoch):
             self.opt.zero_grad(set_to_none=not self.use_graphs)
             gcount = sum(ys[j].shape[0] for j in sel) * (T - 1) * 3       # elements of the GLOBAL batch
             x, y = self._local(xs, ys, sel)
-            lsum = 0.0
             if x is not None and self.use_graphs:
                 t0 = time.time()
-                lsum = float(self._graphed_backward(x, y, gcount))      # grads are (re)written by the replay
+                tot_t += self._graphed_backward(x, y, gcount).to(torch.float64)   # grads are (re)written by the replay
                 t_fwd += time.time() - t0
             elif x is not None:
                 t0 = time.time()
                 ls = self._loss_sum(x, y)
                 t_fwd += time.time() - t0
                 (ls / gcount).backward()
-                lsum = float(ls.detach())
+                tot_t += ls.detach().to(torch.float64)
             if self.world > 1:
                 for p in self.model.parameters():                        # ranks without samples contribute zeros
                     if p.grad is None and p.requires_grad:
                         p.grad = torch.zeros_like(p)
                 sharding.allreduce_flat_grads([p for p in self.model.parameters() if p.grad is not None])
             self.opt.step()
-            tot += self._global_sum(lsum)
             items += gcount
-        return tot / max(items, 1), t_fwd
+        if self.world > 1:
+            torch.distributed.all_reduce(tot_t)
+        return float(tot_t) / max(items, 1), t_fwd
 
     @torch.no_grad()
     def evaluate(self, xs, ys, batch_size):
