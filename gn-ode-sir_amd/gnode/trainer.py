@@ -214,13 +214,6 @@ class Runner:
         graph.replay()
         return ls_out
 
-    def _global_sum(self, value):
-        if self.world == 1:
-            return value
-        t = torch.tensor([value], dtype=torch.float64, device=self.device)
-        torch.distributed.all_reduce(t)
-        return float(t[0])
-
     def train_epoch(self, xs, ys, batch_size, epoch):
         self.model.train()
         items, t_fwd = 0, 0.0
@@ -256,16 +249,22 @@ class Runner:
     @torch.no_grad()
     def evaluate(self, xs, ys, batch_size):
         self.model.eval()
-        tot, items, per_batch = 0.0, 0, []
+        sums, counts = [], []
         T = ys[0].shape[1] if ys else 0
         for sel in self.batches(len(xs), batch_size, False):
             gcount = sum(ys[j].shape[0] for j in sel) * (T - 1) * 3
             x, y = self._local(xs, ys, sel)
-            lsum = self._global_sum(float(self._loss_sum(x, y)) if x is not None else 0.0)
-            tot += lsum
-            items += gcount
-            per_batch.append(lsum / max(gcount, 1))
-        return tot / max(items, 1), per_batch
+            sums.append(self._loss_sum(x, y).to(torch.float64) if x is not None
+                        else torch.zeros((), dtype=torch.float64, device=self.device))
+            counts.append(gcount)
+        if not sums:
+            return 0.0, []
+        allsum = torch.stack(sums)                                   # one read-back for the whole pass
+        if self.world > 1:
+            torch.distributed.all_reduce(allsum)
+        vals = allsum.cpu().tolist()
+        per_batch = [v / max(c, 1) for v, c in zip(vals, counts)]
+        return sum(vals) / max(sum(counts), 1), per_batch
 
 
 # --------------------------------------------------------------------------- single-graph entry (ode_nn_ngraph_sim.py:323-486)
