@@ -81,16 +81,15 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import gnode_oracle as O
-    from gnode import _lib, ops
+    from gnode import _lib, ops, synth
     from gnode.graph import DeviceGraph
 
     lib = _lib.load()
     n, H, B = args.nodes, args.hidden, args.samples
-    rp, ci, _ = O.er_graph(n, args.edges, seed=0)
+    rp, ci = synth.er_csr(n, args.edges, seed=0)
     nnz = int(ci.shape[0])
-    P = O.init_params(H, seed=0)
-    x_host = O.make_samples(n, B, H, seed=1000 + rank)            # each rank its own samples
+    P = synth.linear_params(H, seed=0)
+    x_host = synth.samples(n, B, H, seed=1000 + rank)            # each rank its own samples
     grid = ops.time_grid(args.maxTime, args.deltaT)
     dts = ops.step_sizes(grid)
     n_steps = int(dts.shape[0])
@@ -189,6 +188,7 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import gnode_oracle as O                 # the CPU checker: imported for this leg only
         cores = O.usable_cores()                 # the cgroup CPU share, not the 256 visible cores
         torch.set_num_threads(cores)
         cs = min(args.cpu_steps, n_steps)

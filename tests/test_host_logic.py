@@ -86,3 +86,16 @@ def test_create_graph_csr_cache_roundtrip(tmp_path):
     assert np.array_equal(ode_nn._edge_arrays(G1), ode_nn._edge_arrays(G2))
     G3, _, _ = ode_nn.create_graph(0, base)                      # default: the reference's own route
     assert not isinstance(G3, ode_nn.CsrGraph)
+
+
+def test_synth_inputs_match_oracle_generators():
+    """bench.py builds its inputs with gnode.synth (the oracle is only touched by its cpu_baseline leg); the two
+    generators must stay identical so that the CPU baseline and the parity tests see the same workload."""
+    import gnode_oracle as O
+    from gnode import synth
+    rp, ci = synth.er_csr(3000, 17000, seed=3)
+    rp2, ci2, _ = O.er_graph(3000, 17000, seed=3)
+    assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+    P, P2 = synth.linear_params(64, seed=5), O.init_params(64, seed=5)
+    assert set(P) == set(P2) and all(np.array_equal(P[k], P2[k]) for k in P)
+    assert np.array_equal(synth.samples(77, 3, 16, seed=2), O.make_samples(77, 3, 16, seed=2))
