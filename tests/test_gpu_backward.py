@@ -238,3 +238,38 @@ def test_every_degree_forward_and_backward(H, dev):
         den = max(float(np.abs(want[k]).max()), 1e-3 * scale) + 1e-30
         err = float(np.max(np.abs(got[k].cpu().numpy().astype(np.float64) - want[k]))) / den
         assert err <= 2e-4, f"{k}: rel err {err:.2e}"
+
+
+def test_backward_full_size_properties(dev):
+    """BASELINE's 75k-node graph is too large for the float64 autograd checker to be quick; size-independent
+    properties instead: the gradient map is LINEAR in the output cotangents (grads(2g) = 2 grads(g),
+    grads(g1 + g2) = grads(g1) + grads(g2)) and bitwise reproducible run to run."""
+    import torch
+    import gnode_oracle as O
+    from gnode import ops
+    from gnode.graph import DeviceGraph
+    n, m, B, H, maxTime, deltaT = 75000, 500000, 1, 64, 3, 0.5
+    rp, ci, _ = O.er_graph(n, m, seed=0)
+    P = O.init_params(H, seed=0)
+    x = O.make_samples(n, B, H, seed=4)
+    g = DeviceGraph(rp, ci)
+    params = {k: torch.from_numpy(v).to(dev) for k, v in P.items()}
+    x2d = torch.from_numpy(x).to(dev).reshape(B * n, 3 + H)
+    dts = ops.step_sizes(O.time_grid(maxTime, deltaT))
+    G = len(dts) + 1
+    _, _, _, sol = ops.forward(g, x2d, params, dts, "euler", None, want_sol=True)
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    g1 = [torch.randn(G, B * n, generator=gen).to(dev) for _ in range(3)]
+    g2 = [torch.randn(G, B * n, generator=gen).to(dev) for _ in range(3)]
+    r1 = ops.backward(g, x2d, params, dts, "euler", None, sol, *g1)
+    r1b = ops.backward(g, x2d, params, dts, "euler", None, sol, *g1)
+    r2 = ops.backward(g, x2d, params, dts, "euler", None, sol, *g2)
+    rs = ops.backward(g, x2d, params, dts, "euler", None, sol, *[a + b for a, b in zip(g1, g2)])
+    rd = ops.backward(g, x2d, params, dts, "euler", None, sol, *[2 * a for a in g1])
+    for k in r1:
+        assert torch.equal(r1[k], r1b[k]), k                                   # bitwise reproducible
+        if k == "linearS2.bias":                                               # exact gradient 0 (softmax shift invariance): pure round-off
+            continue
+        scale = float(max(r1[k].abs().max(), r2[k].abs().max())) + 1e-30
+        assert float((rd[k] - 2 * r1[k]).abs().max()) <= 2e-5 * scale, k       # homogeneity (x2 is exact up to reduction order)
+        assert float((rs[k] - (r1[k] + r2[k])).abs().max()) <= 2e-4 * scale, k  # additivity, fp32 sums over 75k rows x 6 points
