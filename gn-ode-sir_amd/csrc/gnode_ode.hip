@@ -27,7 +27,7 @@ void gnode_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gnode_last_error(void) { return g_err; }
-extern "C" int gnode_version(void) { return 100; }
+extern "C" int gnode_version(void) { return 101; }   // 101: + gnode_dmp_f32, gnode_meanfield_f64
 
 // --------------------------------------------------------------------------- instrumentation
 // HIP-event pairs around every launch of the two step kernels while enabled
