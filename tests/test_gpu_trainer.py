@@ -159,3 +159,44 @@ def test_two_rank_entry_point(tmp_path, dev):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     df = pd.read_csv(tmp_path / "multi-graph-1" / "Experiments-seed2-toy" / "Metrics-trials-toy")
     assert len(df) == 1 and np.isfinite(df["val_loss"][0]) and np.isfinite(df["test_loss"][0])
+
+
+def test_runner_loss_matches_reference_epoch_loops(dev):
+    """SURVEY 8a row A6 through the PRODUCT's code: Runner._loss_sum, train_epoch and evaluate against the numbers
+    the reference's own train() / test() loops (ode_nn_ngraph_sim.py:208-296; loss expression :234, element
+    weighting :248-249, :265-266, :290-294) produced on the same weights, samples and labels
+    (tests/golden/make_golden_fullsize.py -> loss_epoch_karate.npz).  lr = 0 on both sides, so the weights
+    stay put and the epoch mean is independent of the shuffle."""
+    import torch
+    import scipy.sparse as sp
+    import gnode_oracle as O
+    from gnode import synth
+    from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
+    from gnode.trainer import Runner
+    from golden.labels import closed_form_labels
+    d = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_epoch_karate.npz")))
+    n, H, maxTime, deltaT, NS = int(d["n"]), int(d["H"]), int(d["maxTime"]), float(d["deltaT"]), int(d["NS"])
+    rp, ci = O.csr_from_edges(n, d["edges"])
+    A = sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n))
+    P = synth.linear_params(H, seed=int(d["param_seed"]))
+    x = torch.from_numpy(synth.samples(n, NS, H, seed=int(d["sample_seed"])))
+    y = torch.from_numpy(closed_form_labels(NS, n, maxTime))
+    xs, ys = [x[i] for i in range(NS)], [y[i] for i in range(NS)]
+    for use_graphs in (False, True):                      # eager loop and HIP-graph replay take different code paths
+        model = ODEBlock(maxTime, deltaT, n, [0], H, ODEfunc(A, 0.2, 0.1, H, dev), dev).to(dev)
+        model.load_state_dict({**model.state_dict(), **{k: torch.from_numpy(v) for k, v in P.items()}})
+        run = Runner(model, 0.0, maxTime, deltaT, dev, stack=True, use_graphs=use_graphs)
+        # one batch: the loss SUM over elements / element count == the reference's criterion value (:234)
+        xb, yb = torch.stack(xs[:2]).to(dev), torch.cat(ys[:2], 0).to(dev)
+        with torch.no_grad():
+            ls = float(run._loss_sum(xb, yb)) / (2 * n * (maxTime - 1) * 3)
+        assert abs(ls - float(d["test_all"][0])) <= 1e-6
+        tr, _ = run.train_epoch(xs, ys, 2, epoch=0)       # batches of 2, 2, 1 in a shuffled order
+        assert abs(tr - float(d["train_loss"])) <= 1e-6
+        sd = model.state_dict()
+        assert all(torch.equal(sd[k].cpu(), torch.from_numpy(v)) for k, v in P.items())      # lr = 0: nothing moved
+        va, _ = run.evaluate(xs, ys, 3)
+        assert abs(va - float(d["val_loss"])) <= 1e-6
+        te, per = run.evaluate(xs, ys, 2)
+        assert abs(te - float(d["test_loss"])) <= 1e-6
+        assert np.max(np.abs(np.asarray(per) - d["test_all"])) <= 1e-6
