@@ -40,6 +40,19 @@ def algorithmic_bytes_per_sample_step(n, nnz, H, projected_R=True):
     return nnz * 4 + (n + 1) * 4 + nnz * H * 4 + 6 * n * H * 4 + r_bytes
 
 
+def self_launch(n_gpus: int) -> int:
+    """Parent side of `python bench.py --gpus N` (N > 1) without an outer launcher.  No HIP call happens in this
+    process: the ranks are children started by torch.distributed.run on a free loopback port."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,15 +70,18 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=59, help="Euler steps of the bounded CPU-baseline sample")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` typed as is: start one FRESH rank per GPU (torch.distributed.run children of this
+        # process, which has not touched the GPU and never will), pass rank 0's JSON line through, exit with their code.
+        sys.exit(self_launch(args.gpus))
+
+    import torch
+    import torch.distributed as dist
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus})")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the GN-ODE path has no CPU fallback)")
     # one rank per GPU; the modulo only matters for rehearsals with more ranks than GPUs on a dev box

@@ -91,7 +91,7 @@ def sir_counts_coins(n, table: np.ndarray, seed_set, beta, gamma, sims, T, coins
     return counts, int(used.value)
 
 
-def sir_torch(G, seed_set, beta, gamma, sims=10000, T=20, rng_seed=None, coins=None):
+def sir_torch(G, seed_set, beta, gamma, sims=10000, T=20, rng_seed=None, coins=None, normalize_t0=False):
     """Monte-Carlo SIR label generator, reference ode_nn.py:30-88.
 
     Returns (S, I, R) numpy float64 COUNTS of shape [1, T, n] exactly like the
@@ -102,6 +102,11 @@ def sir_torch(G, seed_set, beta, gamma, sims=10000, T=20, rng_seed=None, coins=N
     from torch's CPU generator so `torch.manual_seed` governs reproducibility as it
     does for the reference's `torch.rand` (:65,:70).  `coins=` (a recorded stream)
     switches to the bit-exact parity mode.
+
+    normalize_t0 (extension): the reference ASSIGNS row 0 in every trajectory
+    (:55-56) instead of accumulating it, so after the caller's `/sims` that row reads 1/sims, not 1 (the loss
+    skips t = 0, so it is invisible there).  False (default) reproduces the reference's counts exactly;
+    True scales row 0 by `sims` so that counts/sims is the initial state itself.
     """
     n = G.number_of_nodes()
     if coins is not None:
@@ -116,6 +121,8 @@ def sir_torch(G, seed_set, beta, gamma, sims=10000, T=20, rng_seed=None, coins=N
         counts = sir_counts(_device_graph_for(G), seed_set, beta, gamma, sims, T, rng_seed)
     c = counts.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     c = c.astype(np.float64)
+    if normalize_t0:
+        c[:, 0] *= float(sims)
     return c[0][None], c[1][None], c[2][None]
 
 

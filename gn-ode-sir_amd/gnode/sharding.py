@@ -51,18 +51,29 @@ def world_info():
     return 0, 1
 
 
+def collectives_on() -> bool:
+    """True when the data-path collectives must run: a process group exists and either it has more than one rank
+    or GNODE_FORCE_COLLECTIVE=1 (single-GPU rehearsal of the RCCL calls: a world of one still goes through
+    ncclAllReduce, so the backend, the dtypes and the stream handling are exercised on a one-GPU box)."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("GNODE_FORCE_COLLECTIVE", "0") == "1"
+
+
 def allreduce_counts(counts: torch.Tensor) -> torch.Tensor:
-    """Sum Monte-Carlo count shards [3,T,n] over ranks.  Row 0 of S and I is ASSIGNED by
-    every shard (reference quirk, ode_nn.py:55-56), so it is restored after the sum."""
-    rank, world = world_info()
-    if world == 1:
+    """Sum Monte-Carlo count shards [3,T,n] over ranks (int32 holding uint32 bit patterns: two's-complement
+    addition is the same operation).  Row 0 is ASSIGNED, not accumulated (reference quirk, ode_nn.py:55-56):
+    only rank 0 -- which owns trajectory 0 whenever there is any trajectory at all (shard_range hands the
+    remainder to the low ranks) -- contributes it, so a rank whose shard is empty cannot disturb it."""
+    if not collectives_on():
         return counts
-    row0 = counts[:, 0].clone()
-    work = counts.to(torch.int64) if counts.dtype == torch.int32 and not counts.is_cuda else counts
+    if dist.get_rank() != 0:
+        counts[:, 0] = 0
+    work = counts.to(torch.int64) if counts.dtype == torch.int32 and not counts.is_cuda else counts   # gloo has no int32 sum on some builds
     dist.all_reduce(work, op=dist.ReduceOp.SUM)
     if work is not counts:
         counts.copy_(work.to(counts.dtype))
-    counts[:, 0] = row0
     return counts
 
 
@@ -70,12 +81,14 @@ def allreduce_flat_grads(params, scale: float = 1.0):
     """One flat-buffer all-reduce(sum) of every parameter gradient (19 KB for H=64), then
     scale (e.g. 1/global element count to keep the reference's element-mean L1 semantics,
     ode_nn_ngraph_sim.py:248-249)."""
-    rank, world = world_info()
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
+    on = collectives_on()
+    if not on and scale == 1.0:
+        return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    if world > 1:
+    if on:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if scale != 1.0:
         flat.mul_(scale)

@@ -64,14 +64,15 @@ def load_SIR_labels(dataset, path_to_save, G, I_indices, beta, gamma, sim, maxTi
     rank, world = sharding.world_info()
     ps = label_paths(dataset, path_to_save, I_indices)
     have = os.path.exists(ps[0])
-    if world > 1:
+    coll = sharding.collectives_on()
+    if coll:
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         flag = torch.tensor([1 if have else 0], device=dev)
         torch.distributed.broadcast(flag, src=0)
         have = bool(flag.item())
     if have:
         return tuple(pickle.load(open(p, "rb")) for p in ps)
-    if world == 1:
+    if not coll:
         S, I, R = sir_torch(G, I_indices, beta, gamma, sim, maxTime)
         out = (S[0] / sim, I[0] / sim, R[0] / sim)
     else:
@@ -143,8 +144,9 @@ class Runner:
         self.opt = torch.optim.Adam(model.parameters(), lr=lr, fused=True) if on_gpu else torch.optim.Adam(model.parameters(), lr=lr)
         self.rows = ops.subsample_rows(maxTime, deltaT)
         self.rank, self.world = sharding.world_info()
+        self.collective = sharding.collectives_on()      # world > 1, or a forced single-rank rehearsal of the RCCL calls
         seed = torch.randint(0, 2**31 - 1, (1,))
-        if self.world > 1:
+        if self.collective:
             seed = seed.to(device)
             torch.distributed.broadcast(seed, src=0)
             for p in model.parameters():                 # every rank starts from rank 0's initialisation
@@ -235,14 +237,14 @@ class Runner:
                 t_fwd += time.time() - t0
                 (ls / gcount).backward()
                 tot_t += ls.detach().to(torch.float64)
-            if self.world > 1:
+            if self.collective:
                 for p in self.model.parameters():                        # ranks without samples contribute zeros
                     if p.grad is None and p.requires_grad:
                         p.grad = torch.zeros_like(p)
                 sharding.allreduce_flat_grads([p for p in self.model.parameters() if p.grad is not None])
             self.opt.step()
             items += gcount
-        if self.world > 1:
+        if self.collective:
             torch.distributed.all_reduce(tot_t)
         return float(tot_t) / max(items, 1), t_fwd
 
@@ -260,7 +262,7 @@ class Runner:
         if not sums:
             return 0.0, []
         allsum = torch.stack(sums)                                   # one read-back for the whole pass
-        if self.world > 1:
+        if self.collective:
             torch.distributed.all_reduce(allsum)
         vals = allsum.cpu().tolist()
         per_batch = [v / max(c, 1) for v, c in zip(vals, counts)]

@@ -51,6 +51,12 @@ def _worker(rank, world, port, q):
         sh.allreduce_counts(ct)
         whole = O.sir_philox(n, rp, ci, [2, 9], 0.4, 0.2, sims, T, rng_seed=77)
         ok_mc = np.array_equal(ct.numpy().astype(np.uint32), whole)
+        # fewer trajectories than ranks: rank 1's shard is EMPTY and must not disturb the assigned row 0
+        slo, shi = sh.shard_range(1, rank, world)
+        c1 = O.sir_philox(n, rp, ci, [2, 9], 0.4, 0.2, shi - slo, T, rng_seed=5, sim_offset=slo) if shi > slo else np.zeros((3, T, n), np.uint32)
+        ct1 = torch.from_numpy(c1.astype(np.int64))
+        sh.allreduce_counts(ct1)
+        ok_mc = ok_mc and np.array_equal(ct1.numpy().astype(np.uint32), O.sir_philox(n, rp, ci, [2, 9], 0.4, 0.2, 1, T, rng_seed=5))
         # ---- flat gradient all-reduce
         w = torch.nn.Linear(4, 3)
         for p_ in w.parameters():
