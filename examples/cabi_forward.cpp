@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
         dev(b2, &db2) || dev(x, &dx)) return 1;
     const int G = n_steps + 1;
     HK(hipMalloc(&dout, sizeof(float) * 3 * G * rows));
-    const size_t ws_bytes = gnode_forward_workspace_bytes(rows, H, 0);
+    const size_t ws_bytes = gnode_forward_workspace_bytes(g, rows, H, 0);
     HK(hipMalloc(&ws, ws_bytes));
     gnode_params p = {dW, db, dw1, db1, dw3, db3, dw2, db2};
     std::vector<float> dt(n_steps, 0.5f);

@@ -25,5 +25,5 @@ int gn_launch_tiny_bwd64(const gnode_graph_s* g, long rows, const float* x, cons
                          const float* gI, const float* gR, float* part, hipStream_t st);
 
 // H = 128: a += dt dpre W, gW, gb on the matrix cores (gnode_h128.hip); raises *slots_used to its grid size
-int gn_launch_bwd_mlp128(const float* dpre, const float* Ysol, const float* W, float dt, float* a, long rows, float* part,
-                         int* slots_used, hipStream_t st);
+int gn_launch_bwd_mlp128(const gnode_graph_s* g, const float* dpre, const float* Ysol, const float* W, float dt, float* a, long rows,
+                         float* part, int* slots_used, hipStream_t st);

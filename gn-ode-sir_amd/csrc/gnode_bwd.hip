@@ -28,7 +28,6 @@
 #include "gnode_mfma64.h"
 #include "gnode_head64.h"
 #include <algorithm>
-#include <cstdlib>
 
 __device__ __forceinline__ float4 ld4b(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4b(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -348,117 +347,6 @@ __device__ __forceinline__ void gather2_row64(const int* __restrict__ rowptr, co
     }
 }
 
-// One launch per backward interval: both gathers, dpre, gW/gb accumulation and a += dt dpre W, tile by tile.
-__global__ __launch_bounds__(256) void k_bwd_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
-                                                    long rows, int tiles_per_sample, long total_tiles,
-                                                    const float* __restrict__ Z, const float* __restrict__ q,
-                                                    const float* __restrict__ Ysol, const float* __restrict__ W,
-                                                    const float* __restrict__ beta, const float* __restrict__ gamma,
-                                                    float dt, float* __restrict__ a, float* __restrict__ part_all,
-                                                    const int* __restrict__ hubidx, const float* __restrict__ AIhub,
-                                                    const float* __restrict__ GQhub, int n_hub) {
-    __shared__ __attribute__((aligned(16))) float WlT[64 * TS];
-    __shared__ __attribute__((aligned(16))) float Dt[2][TILE_ROWS * TS];
-    __shared__ __attribute__((aligned(16))) float Yt[2][TILE_ROWS * TS];
-    const PartLayout L{64};
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
-    const int i = lane & 15, kq = lane >> 4;
-    load_W_to_lds<true>(W, WlT);
-    const size_t slab = (size_t)rows * 64;
-    const float* ZS = Z; const float* ZI = Z + slab;
-    const int lr[2] = {w * 8 + g, w * 8 + 4 + g};
-    f32x4 accW[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) accW[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float accb = 0.f;
-    for (long t = blockIdx.x; t < total_tiles; t += gridDim.x) {
-        const long b = t / tiles_per_sample;
-        const int tile = (int)(t - b * tiles_per_sample);
-        const long base = b * n;
-        bool valid[2]; size_t off[2]; float4 aS[2], aI[2];
-        __syncthreads();                                   // previous tile fully consumed (and W staged)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int node = tile * TILE_ROWS + lr[p];
-            valid[p] = node < n;
-            off[p] = (size_t)(base + node) * 64 + 4 * sub;
-            float4 ai, gq;
-            const int hub = (hubidx && valid[p]) ? hubidx[node] : -1;
-            if (hub >= 0) {
-                ai = ld4g(AIhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
-                gq = ld4g(GQhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
-            } else {
-                gather2_row64(rowptr, col, ZI + (size_t)base * 64, q + (size_t)base * 64, node, valid[p], sub, ai, gq);
-            }
-            float4 dS = zero4(), dI = zero4();
-            aS[p] = zero4(); aI[p] = zero4();
-            if (valid[p]) {
-                const float bt = beta[base + node], gm = gamma[base + node];
-                aS[p] = ld4g(a + off[p]); aI[p] = ld4g(a + slab + off[p]);
-                const float4 aR = ld4g(a + 2 * slab + off[p]);
-                const float4 zs = ld4g(ZS + off[p]), zi = ld4g(ZI + off[p]);
-#define GN_DP(c)                                                               \
-                {                                                              \
-                    const float v = bt * (aI[p].c - aS[p].c);                  \
-                    dS.c = (v * ai.c) * (zs.c * (1.0f - zs.c));                \
-                    dI.c = (gq.c + gm * (aR.c - aI[p].c)) * (zi.c * (1.0f - zi.c)); \
-                }
-                GN_DP(x) GN_DP(y) GN_DP(z) GN_DP(w)
-#undef GN_DP
-            }
-            *reinterpret_cast<float4*>(&Dt[0][lr[p] * TS + 4 * sub]) = dS;
-            *reinterpret_cast<float4*>(&Dt[1][lr[p] * TS + 4 * sub]) = dI;
-            *reinterpret_cast<float4*>(&Yt[0][lr[p] * TS + 4 * sub]) = valid[p] ? ld4g(Ysol + off[p]) : zero4();
-            *reinterpret_cast<float4*>(&Yt[1][lr[p] * TS + 4 * sub]) = valid[p] ? ld4g(Ysol + slab + off[p]) : zero4();
-        }
-        __syncthreads();
-#pragma unroll
-        for (int X = 0; X < 2; ++X) {
-#pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) {
-                const int rr = 4 * s8 + kq;
-                const float av = Dt[X][rr * TS + 16 * w + i];
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-                    accW[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Yt[X][rr * TS + 16 * kt + i], accW[kt], 0, 0, 0);
-            }
-        }
-        if (threadIdx.x < 64) {
-            float sacc = 0.f;
-            for (int rr = 0; rr < TILE_ROWS; ++rr) sacc += Dt[0][rr * TS + threadIdx.x] + Dt[1][rr * TS + threadIdx.x];
-            accb += sacc;
-        }
-        __syncthreads();
-        mfma_tile<false>(Dt[0], WlT, Yt[0], 0.f, w, lane);
-        mfma_tile<false>(Dt[1], WlT, Yt[1], 0.f, w, lane);
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            if (!valid[p]) continue;
-            const float4 gS = *reinterpret_cast<const float4*>(&Yt[0][lr[p] * TS + 4 * sub]);
-            const float4 gI = *reinterpret_cast<const float4*>(&Yt[1][lr[p] * TS + 4 * sub]);
-            aS[p].x += dt * gS.x; aS[p].y += dt * gS.y; aS[p].z += dt * gS.z; aS[p].w += dt * gS.w;
-            aI[p].x += dt * gI.x; aI[p].y += dt * gI.y; aI[p].z += dt * gI.z; aI[p].w += dt * gI.w;
-            st4g(a + off[p], aS[p]); st4g(a + slab + off[p], aI[p]);
-        }
-    }
-    float* part = part_all + (size_t)blockIdx.x * L.total();
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-            part[L.oW() + (16 * w + 4 * kq + reg) * 64 + 16 * kt + i] += dt * accW[kt][reg];
-    if (threadIdx.x < 64) part[L.ob() + threadIdx.x] += dt * accb;
-}
-
-// --------------------------------------------------------------------------- ONE launch per backward interval (H = 64)
-// k_bwd_step64's work for interval i, then -- every piece of it row-local -- what used to be two more launches:
-//   * the head's VJP at grid point i-1 (dL/dsol[i-1] enters a while the rows are still in registers), and
-//   * Z(y_{i-1}) and q = beta (a_I - a_S) Z_S for the NEXT interval, written to the other half of the double-buffered
-//     gather tables (the forward's P4 trick), so no separate node-MLP launch exists in the sweep.
-// One copy of W in LDS serves both contractions (X W^T for Z, X W for g_Y): 52 KB, 3 workgroups per CU.
-// workgroups per CU of the 16-row-tile form.  Every workgroup owns one slot of the partial-gradient buffer, which has
-// BWD_NWG slots: the grid may never exceed that (a 4-per-CU grid of 1024 would write past the buffer).
 #ifndef GN_BWD_RPG1_OCC
 #define GN_BWD_RPG1_OCC 3
 #endif
@@ -890,7 +778,8 @@ __global__ __launch_bounds__(256) void k_reduce_parts(const float* __restrict__ 
 }
 
 // --------------------------------------------------------------------------- host
-int gn_launch_mlp_any(const float* X, const float* W, const float* b, float* Z, long nrows, int H, hipStream_t st);
+int gn_launch_mlp_any(const gnode_graph_s* g, const float* X, const float* W, const float* b, float* Z, long nrows, int H,
+                      hipStream_t st);
 
 static int lpr_of(int H) {
     int need = H / 4, l = 1;
@@ -916,12 +805,23 @@ __global__ void k_extract_bg(const float* __restrict__ bgslab, long rows, int H,
     gamma[r] = bgslab[(size_t)r * H + 1];
 }
 
-extern "C" size_t gnode_backward_workspace_bytes(int64_t rows, int32_t H) {
+static size_t backward_fixed_bytes(int64_t rows, int32_t H) {
     const PartLayout L{H};
     const size_t slab = gn_align((size_t)rows * H * sizeof(float));
     // a[3], Z[2], q[1], dpre[2] slabs + beta, gamma + partial buffer + reduced gradient vector
     return 8 * slab + 2 * gn_align((size_t)rows * sizeof(float)) +
            gn_align((size_t)BWD_NWG * L.total() * sizeof(float)) + gn_align((size_t)L.total() * sizeof(float));
+}
+
+extern "C" size_t gnode_backward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H) {
+    if (!g || rows <= 0 || H <= 0) return 0;
+    return backward_fixed_bytes(rows, H) + gn_hub_scratch_bytes(g, rows / g->n, H, 2);     // two tables per hub pass
+}
+
+// dynamic LDS above 64 KB (the five-launch generic path at H > 100) needs the attribute once per device
+int gn_bwd_set_attributes() {
+    GN_HIP(hipFuncSetAttribute((const void*)k_bwd_mlp<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
 }
 
 extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
@@ -936,8 +836,8 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     GN_CHECK_ARG(grads->odefunc_linear_weight && grads->odefunc_linear_bias && grads->linearS1_weight &&
                      grads->linearS1_bias && grads->linear3_weight && grads->linear3_bias && grads->linearS2_weight &&
                      grads->linearS2_bias, "gnode_backward_f32: null gradient pointer");
-    if (workspace_bytes < gnode_backward_workspace_bytes(rows, H)) {
-        gnode_set_error("gnode_backward_f32: workspace %zu < %zu", workspace_bytes, gnode_backward_workspace_bytes(rows, H));
+    if (workspace_bytes < gnode_backward_workspace_bytes(g, rows, H)) {
+        gnode_set_error("gnode_backward_f32: workspace %zu < %zu", workspace_bytes, gnode_backward_workspace_bytes(g, rows, H));
         return GNODE_ERR_WORKSPACE;
     }
     const int G = n_steps + 1;
@@ -958,6 +858,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     float* gamma = (float*)(ws + 8 * slab_b + vec_b);
     float* part = (float*)(ws + 8 * slab_b + 2 * vec_b);
     float* red = (float*)(ws + 8 * slab_b + 2 * vec_b + gn_align((size_t)BWD_NWG * L.total() * sizeof(float)));
+    void* hub_scratch = ws + backward_fixed_bytes(rows, H);
     int slots_used = 1;                                  // highest workgroup slot any launch wrote, for the final reduction
     const bool tiny = gn_tiny_bwd64_ok(g, rows, H, n_steps);
     if (tiny) {
@@ -991,8 +892,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     };
     if (int e = head(G - 1)) return e;
     const size_t mlp_lds = ((size_t)H * H + (size_t)4 * rpw * H) * sizeof(float);
-    static const bool fuse64 = [] { const char* e = getenv("GNODE_BWD_FUSE"); return !(e && e[0] == '0'); }();
-    if (H == 64 && fuse64 && n_steps >= 1) {
+    if (H == 64 && n_steps >= 1) {
         // one launch per interval: a[3] | Z_S | Z_I(0) | q(0) | Z_I(1) | q(1)  (Z_S is row-local, the gather tables ping-pong)
         float* ZS = Z; float* ZIb[2] = {Z + slab_b / sizeof(float), dpre};
         float* Qb[2] = {q, dpre + slab_b / sizeof(float)};
@@ -1000,20 +900,17 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         hipLaunchKernelGGL(k_mlp64_q, dim3((unsigned)std::min<long>(mt, 1024)), dim3(256), 0, st, sol + (size_t)(G - 1) * 4 * slab,
                            p->odefunc_linear_weight, p->odefunc_linear_bias, Z, a, beta, q, (long)rows);
         GN_LAUNCH_CHECK();
-        // 3 workgroups per CU (the LDS limit) cost 17 spilled dwords per lane, 2 run spill-free: measured on the 75k
-        // graph, 4 samples, 481 vs 548 us per interval (unfused three-launch form: 563) -> 3
-        static const int occ = [] { const char* e = getenv("GNODE_BWD_OCC"); return (e && e[0] == '2') ? 2 : 3; }();
-        static const int rpg = [] { const char* e = getenv("GNODE_BWD_RPG"); return (e && e[0] == '2') ? 2 : 1; }();
-        auto fused_kernel = rpg == 1 ? k_bwd_fused64<GN_BWD_RPG1_OCC, 1> : (occ == 3 ? k_bwd_fused64<3, 2> : k_bwd_fused64<2, 2>);
-        const int tr = 16 * rpg;
-        const int tps = (g->n + tr - 1) / tr;
+        // 16-row tiles at 3 workgroups per CU (measured on the 75k graph, 4 samples: 32-row tiles at 3 / 2 per CU 481 / 548 us
+        // per interval, the unfused three-launch form 563; 16-row tiles 451)
+        auto fused_kernel = k_bwd_fused64<GN_BWD_RPG1_OCC, 1>;
+        const int tps = (g->n + 15) / 16;
         const long total = (long)(rows / g->n) * tps;
-        const int grid = (int)std::min<long>(std::min<long>((rpg == 1 ? GN_BWD_RPG1_OCC : occ) * 256, BWD_NWG), total);
+        const int grid = (int)std::min<long>(std::min<long>((long)GN_BWD_RPG1_OCC * g->num_cu, BWD_NWG), total);
         slots_used = std::max(slots_used, grid);
         for (int i = G - 1; i >= 1; --i) {
             const int cur = (G - 1 - i) & 1;
             const float *AIhub = nullptr, *GQhub = nullptr;
-            if (int e = gn_hub_gather(g, rows / g->n, 64, ZIb[cur], Qb[cur], &AIhub, &GQhub, st)) return e;
+            if (int e = gn_hub_gather(g, rows / g->n, 64, ZIb[cur], Qb[cur], hub_scratch, &AIhub, &GQhub, st)) return e;
             const int s = slot_of(i - 1);
             const float* gSs = s >= 0 ? gS + (size_t)s * rows : nullptr;
             hipLaunchKernelGGL(fused_kernel, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, tps, total, ZS,
@@ -1024,12 +921,12 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                                p->linearS2_weight, p->linearS2_bias, g->hubidx, AIhub, GQhub, g->n_hub, i > 1 ? 1 : 0);
             GN_LAUNCH_CHECK();
         }
-    } else if (H <= 32 && fuse64 && n_steps >= 1) {
+    } else if (H <= 32 && n_steps >= 1) {
         // small hidden sizes: the same one-launch-per-interval scheme on lane groups (k_bwd_fused_generic)
         float* ZS = Z; float* ZIb[2] = {Z + slab, dpre};
         float* Qb[2] = {q, dpre + slab};
         const float* yl = sol + (size_t)(G - 1) * 4 * slab;
-        if (int e = gn_launch_mlp_any(yl, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
+        if (int e = gn_launch_mlp_any(g, yl, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
         hipLaunchKernelGGL(k_bwd_q, dim3(2048), dim3(256), 0, st, a, Z, beta, q, (long)rows, H);
         GN_LAUNCH_CHECK();
         const size_t fl = std::max((size_t)2 * H * H + (size_t)4 * rpw * H, (size_t)rpw * (4 * H + 12));
@@ -1038,7 +935,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         for (int i = G - 1; i >= 1; --i) {
             const int cur = (G - 1 - i) & 1;
             const float *AIhub = nullptr, *GQhub = nullptr;
-            if (int e = gn_hub_gather(g, rows / g->n, H, ZIb[cur], Qb[cur], &AIhub, &GQhub, st)) return e;
+            if (int e = gn_hub_gather(g, rows / g->n, H, ZIb[cur], Qb[cur], hub_scratch, &AIhub, &GQhub, st)) return e;
             const int s = slot_of(i - 1);
             BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_bwd_fused_generic<LPR>, dim3(grid), dim3(256), fl * sizeof(float), st, g->rowptr,
                                                  g->col, g->n, (long)rows, H, ZS, ZIb[cur], Qb[cur], ZIb[cur ^ 1], Qb[cur ^ 1],
@@ -1054,39 +951,20 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     for (int i = G - 1; i >= 1; --i) {
         const float* yi = sol + (size_t)i * 4 * slab;
         const float dt = dt_host[i - 1];
-        if (H == 64) {
-            const long mt = (2 * rows + TILE_ROWS - 1) / TILE_ROWS;
-            hipLaunchKernelGGL(k_mlp64_q, dim3((unsigned)std::min<long>(mt, 1024)), dim3(256), 0, st, yi, p->odefunc_linear_weight,
-                               p->odefunc_linear_bias, Z, a, beta, q, (long)rows);
-            GN_LAUNCH_CHECK();
-            const int tps = (g->n + TILE_ROWS - 1) / TILE_ROWS;
-            const long total = (long)(rows / g->n) * tps;
-            slots_used = std::max(slots_used, (int)std::min<long>(BWD_NWG, total));
-            const float *AIhub = nullptr, *GQhub = nullptr;
-            if (int e = gn_hub_gather(g, rows / g->n, 64, Z + slab, q, &AIhub, &GQhub, st)) return e;
-            hipLaunchKernelGGL(k_bwd_step64, dim3((unsigned)std::min<long>(BWD_NWG, total)), dim3(256), 0, st, g->rowptr, g->col,
-                               g->n, (long)rows, tps, total, Z, q, yi, p->odefunc_linear_weight, beta, gamma, dt, a, part,
-                               g->hubidx, AIhub, GQhub, g->n_hub);
-            GN_LAUNCH_CHECK();
-        } else {
-            if (int e = gn_launch_mlp_any(yi, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
+        {
+            if (int e = gn_launch_mlp_any(g, yi, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
             hipLaunchKernelGGL(k_bwd_q, dim3(2048), dim3(256), 0, st, a, Z, beta, q, (long)rows, H);
             GN_LAUNCH_CHECK();
             dim3 ggrid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)(rows / g->n));
             const float *AIhub = nullptr, *GQhub = nullptr;
-            if (int e = gn_hub_gather(g, rows / g->n, H, Z + slab, q, &AIhub, &GQhub, st)) return e;
+            if (int e = gn_hub_gather(g, rows / g->n, H, Z + slab, q, hub_scratch, &AIhub, &GQhub, st)) return e;
             BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_bwd_gather<LPR>, ggrid, dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, H,
                                                  a, Z, q, beta, gamma, dpre, g->hubidx, AIhub, GQhub, g->n_hub));
             GN_LAUNCH_CHECK();
             if (H == 128) {
-                if (int e = gn_launch_bwd_mlp128(dpre, yi, p->odefunc_linear_weight, dt, a, rows, part, &slots_used, st)) return e;
+                if (int e = gn_launch_bwd_mlp128(g, dpre, yi, p->odefunc_linear_weight, dt, a, rows, part, &slots_used, st)) return e;
             } else
             BWD_DISPATCH(lpr, {
-                static bool attr_set = false;      // once per instantiation, never inside a stream capture
-                if (mlp_lds > 64 * 1024 && !attr_set) {
-                    GN_HIP(hipFuncSetAttribute((const void*)k_bwd_mlp<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_lds));
-                    attr_set = true;
-                }
                 slots_used = BWD_NWG;
                 hipLaunchKernelGGL(k_bwd_mlp<LPR>, dim3(BWD_NWG), dim3(256), mlp_lds, st, dpre, yi, p->odefunc_linear_weight, dt,
                                    a, (long)rows, H, part);

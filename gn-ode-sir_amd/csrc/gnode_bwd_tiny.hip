@@ -305,9 +305,13 @@ static size_t tiny_bwd_lds_bytes(int n) {
 }
 
 bool gn_tiny_bwd64_ok(const gnode_graph_s* g, long rows, int H, int n_steps) {
-    static const bool on = [] { const char* e = getenv("GNODE_TINY"); return !(e && e[0] == '0'); }();
-    return on && H == 64 && g->n <= 2 * TILE_ROWS && n_steps >= 0 && n_steps <= 128 && rows / g->n <= BWD_NWG &&
+    return H == 64 && g->n <= 2 * TILE_ROWS && n_steps >= 0 && n_steps <= 128 && rows / g->n <= BWD_NWG &&
            tiny_bwd_lds_bytes(g->n) <= 160 * 1024;
+}
+
+int gn_bwd_tiny_set_attributes() {      // once per device, from gnode_graph_create
+    GN_HIP(hipFuncSetAttribute((const void*)k_tiny_bwd64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
 }
 
 int gn_launch_tiny_bwd64(const gnode_graph_s* g, long rows, const float* x, const gnode_params* p, const float* dt_host,
@@ -320,11 +324,6 @@ int gn_launch_tiny_bwd64(const gnode_graph_s* g, long rows, const float* x, cons
     if (out_rows_host) {
         GN_CHECK_ARG(n_out < 32768, "gnode_backward_f32: too many output rows (%d)", n_out);
         for (int i = 0; i < n_out; ++i) sched.slot[out_rows_host[i]] = (short)i;
-    }
-    static bool attr = false;      // once, never inside a stream capture (callers warm up eagerly first)
-    if (!attr) {
-        GN_HIP(hipFuncSetAttribute((const void*)k_tiny_bwd64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     const unsigned B = (unsigned)(rows / g->n);
     const unsigned threads = 256u * (unsigned)((g->n + TILE_ROWS - 1) / TILE_ROWS);

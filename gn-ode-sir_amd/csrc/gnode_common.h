@@ -10,6 +10,8 @@ struct gnode_graph_s {
     int32_t n;
     int64_t nnz;
     int32_t max_degree;
+    int32_t device;   // the HIP device the CSR lives on (current device at gnode_graph_create)
+    int32_t num_cu;   // its compute-unit count: persistent grids are sized from the handle, not from process globals
     int32_t* rowptr;  // device [n+1]
     int32_t* col;     // device [nnz]
     // hub rows (gnode_hub.hip): rows longer than the hub threshold, cut into <= 32-edge segments
@@ -18,14 +20,24 @@ struct gnode_graph_s {
     int32_t* seg_lo;        // device [n_seg]: first CSR position of a segment
     int32_t* seg_hi;        // device [n_seg]: one past its last
     int32_t* hub_seg_ptr;   // device [n_hub+1]: segments of hub h are [ptr[h], ptr[h+1])
-    void* hub_scratch;      // device, grow-only: segment partials + hub sums for the largest batch seen
-    size_t hub_scratch_bytes;
 };
 
 int gn_hub_build(gnode_graph_s* g, const int32_t* rowptr_host);
 void gn_hub_free(gnode_graph_s* g);
-int gn_hub_gather(gnode_graph_s* g, long B, int H, const float* T0, const float* T1, const float** A0, const float** A1,
-                  hipStream_t st);
+// Hub sums of `ntables` (1 or 2) tables for a batch of B samples need this much of the CALLER's workspace (0 for a graph
+// without hub rows); gn_hub_gather carves its segment partials and hub sums from it: no allocation, no
+// synchronisation, nothing retained in the handle.
+size_t gn_hub_scratch_bytes(const gnode_graph_s* g, long B, int H, int ntables);
+int gn_hub_gather(const gnode_graph_s* g, long B, int H, const float* T0, const float* T1, void* scratch, const float** A0,
+                  const float** A1, hipStream_t st);
+
+// per-device one-time setup (dynamic-LDS attributes of every kernel that may need more than 64 KB), run by
+// gnode_graph_create for the current device; each translation unit contributes its kernels
+int gn_device_setup_once(int dev);      // idempotent, locked; returns a gnode_status
+int gn_ode_set_attributes();
+int gn_bwd_set_attributes();
+int gn_bwd_tiny_set_attributes();
+int gn_sir_set_attributes();
 
 void gnode_set_error(const char* fmt, ...);
 

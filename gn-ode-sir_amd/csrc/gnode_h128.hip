@@ -75,18 +75,15 @@ __global__ __launch_bounds__(256) void k_mlp128(const float* __restrict__ X, con
     }
 }
 
-int gn_launch_mlp128(const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st) {
-    const size_t lds = (size_t)(128 + 16) * TS128 * sizeof(float);     // 76 032 B: two workgroups per CU
-    static bool attr = false;                                          // once, never inside a stream capture
-    if (!attr) {
-        GN_HIP(hipFuncSetAttribute((const void*)k_mlp128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+static const size_t kMlp128Lds = (size_t)(128 + 16) * TS128 * sizeof(float);       // 76 032 B: two workgroups per CU
+static const size_t kBwdMlp128Lds = (size_t)(128 + 64) * TS128 * sizeof(float);    // 101 376 B
+
+int gn_h128_set_attributes();   // defined below both kernels
+
+int gn_launch_mlp128(const gnode_graph_s* g, const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st) {
+    const size_t lds = kMlp128Lds;
     const long ntiles = (nrows + 15) / 16;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    hipLaunchKernelGGL(k_mlp128, dim3((unsigned)std::min<long>(ntiles, 2L * cus)), dim3(256), lds, st, X, W, b, Z, nrows);
+    hipLaunchKernelGGL(k_mlp128, dim3((unsigned)std::min<long>(ntiles, 2L * g->num_cu)), dim3(256), lds, st, X, W, b, Z, nrows);
     GN_LAUNCH_CHECK();
     return 0;
 }
@@ -191,19 +188,17 @@ __global__ __launch_bounds__(512) void k_bwd_mlp128(const float* __restrict__ dp
     if (threadIdx.x < 128) part[L.ob() + threadIdx.x] += dt * accb;
 }
 
-int gn_launch_bwd_mlp128(const float* dpre, const float* Ysol, const float* W, float dt, float* a, long rows, float* part,
-                         int* slots_used, hipStream_t st) {
-    const size_t lds = (size_t)(128 + 64) * TS128 * sizeof(float);     // 101 376 B
-    static bool attr = false;
-    if (!attr) {
-        GN_HIP(hipFuncSetAttribute((const void*)k_bwd_mlp128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+int gn_h128_set_attributes() {      // once per device, from gnode_graph_create
+    GN_HIP(hipFuncSetAttribute((const void*)k_mlp128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMlp128Lds));
+    GN_HIP(hipFuncSetAttribute((const void*)k_bwd_mlp128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdMlp128Lds));
+    return 0;
+}
+
+int gn_launch_bwd_mlp128(const gnode_graph_s* g, const float* dpre, const float* Ysol, const float* W, float dt, float* a, long rows,
+                         float* part, int* slots_used, hipStream_t st) {
+    const size_t lds = kBwdMlp128Lds;
     const long ntiles = (rows + 15) / 16;
-    const int grid = (int)std::min<long>(std::min<long>(ntiles, cus), BWD_NWG);     // one slot of the partial buffer per workgroup
+    const int grid = (int)std::min<long>(std::min<long>(ntiles, g->num_cu), BWD_NWG);     // one slot of the partial buffer per workgroup
     *slots_used = std::max(*slots_used, grid);
     hipLaunchKernelGGL(k_bwd_mlp128, dim3(grid), dim3(512), lds, st, dpre, Ysol, W, dt, a, rows, part);
     GN_LAUNCH_CHECK();

@@ -7,11 +7,13 @@ struct Step64Out {
     float* sol;                     // sol[g+1] base ([4*rows, 64]), or null
 };
 
-int gn_launch_mlp64(const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st);
+int gn_h64_set_attributes();    // once per device, from gnode_graph_create
+int gn_launch_mlp64(const gnode_graph_s* g, const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st);
+// ZI / ZI_next: gather tables [rows + 1][64] whose last row is the zero row (gn_launch_prologue64 writes it)
 int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, float* ZI_next, const float* W,
                      const float* bias, const float* beta, const float* gamma, float dt, const gnode_params* p,
-                     float* PR /* [rows][4] projected R state, or null = carry Y_R */, Step64Out out, bool fuse,
-                     hipStream_t st);
+                     float* PR /* [rows][4] projected R state, or null = carry Y_R */, Step64Out out,
+                     void* hub_scratch /* gn_hub_scratch_bytes(g, B, 64, 1) bytes of the caller's workspace */, hipStream_t st);
 
 // single-launch integration for graphs whose per-sample state fits one workgroup's LDS (gnode_h64.hip: k_tiny64)
 bool gn_tiny64_ok(int n, int n_steps, int n_out, bool prj);
@@ -20,8 +22,10 @@ int gn_launch_tiny64(const gnode_graph_s* g, long rows, const float* Y0, const f
                      int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol, hipStream_t st);
 
 // encoder + beta/gamma + trajectory point 0 + read-out at grid point 0 + projected R + Z_I(y_0) in one launch
+// ZI / ZI_alt: the two gather tables, each [rows + 1][64]: row `rows` is the table's ZERO ROW (written here)
 int gn_launch_prologue64(const float* x, const gnode_params* p, float* Y, float* beta, float* gamma, float* sol0, float* ZI,
-                         float* PR, float* S0, float* I0, float* R0, long rows, hipStream_t st);
+                         float* ZI_alt, float* PR, float* S0, float* I0, float* R0, long rows, hipStream_t st);
 
 // H = 128 node MLP on the matrix cores (gnode_h128.hip)
-int gn_launch_mlp128(const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st);
+int gn_h128_set_attributes();   // once per device, from gnode_graph_create
+int gn_launch_mlp128(const gnode_graph_s* g, const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st);

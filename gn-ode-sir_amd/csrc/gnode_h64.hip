@@ -1,75 +1,33 @@
 // H = 64 fast path of the GN-ODE step for MI355X (gfx950).
 //
 // One launch per Euler step (per chunk of samples):
-//   k_step64<FUSE,PRJ,RPG>  persistent 256-thread workgroups walk 16-node tiles (RPG = 1, 5 workgroups per
-//                           CU; RPG = 2: 32-node tiles, 4 per CU):
-//     P1  stage the tile's Y_S rows to LDS (coalesced 16 B/lane, 4 rows per wave
-//         instruction) and pull-gather AI = sum_{c in adj} Z_I[c] with one 16-lane
-//         group per row (column indices broadcast inside the group by DPP
-//         row_newbcast, neighbour rows as 256-B coalesced reads, 8 in flight);
-//     P2  Z_S = sigmoid(Y_S W^T + b) on the fp32 matrix cores
-//         (v_mfma_f32_16x16x4_f32, exact fp32), W^T resident in LDS for the
-//         whole launch, each wave a 16-column slab of the tile's output;
-//     P3  SIR derivative + Euler update of Y_S, Y_I, Y_R in place, optional
-//         trajectory write, fused read-out head + 3-way softmax (16-lane DPP
-//         reductions, no LDS traffic);
-//     P4  (FUSE) Z_I of the NEXT step from the freshly updated Y_I rows, again on
-//         the matrix cores, so the separate node-MLP launch disappears and
-//         Y_S / Y_I are read once per step.
-//     PRJ (inference): the R compartment is carried as w3 . Y_R (4 floats per row) -- it only
-//         feeds the read-out, whose first layer is linear.
-//     Rows longer than the hub threshold arrive pre-summed from gnode_hub.hip.
+//   k_step64<PRJ>    persistent 256-thread workgroups (4 per CU) walk 16-node tiles, three tiles in flight per
+//                    workgroup (software pipeline, see the kernel's header comment):
+//       gather   AI = sum_{c in adj} Z_I[c], one 16-lane group per row, neighbour rows as 256-B coalesced reads,
+//                eight in flight per group rolling through eight registers, column ids broadcast inside the group
+//                by DPP row_newbcast fused into the address add, ascending-column sum (the CPU scatter_add_ order);
+//       update   SIR derivative + Euler update of Y_S, Y_I, (Y_R) in place, optional trajectory write, fused read-out
+//                head + 3-way softmax (16-lane DPP reductions);
+//       MLPs     Z_I of the NEXT step from the freshly updated Y_I rows and Z_S of the NEXT tile from its Y_S rows in
+//                ONE fp32 matrix-core phase (v_mfma_f32_16x16x4_f32, exact fp32), W^T resident in LDS for the whole
+//                launch -- no separate node-MLP launch, Y_S / Y_I read once per step.
+//       PRJ (inference): the R compartment is carried as w3 . Y_R (4 floats per row) -- it only feeds the read-out,
+//                whose first layer is linear.
+//       Rows longer than the hub threshold arrive pre-summed from gnode_hub.hip.
 //   k_tiny64<PRJ>    graphs that fit one workgroup's LDS: ALL Euler steps in one launch.
-//   k_mlp64          the same MFMA tile engine alone (RHS API, step 0, RK4 stages).
+//   k_mlp64          the MFMA tile engine alone (RHS API, RK4 stages, backward start-up).
+//   k_prologue64     everything before the first step in one launch.
 //
 // Reference semantics: ode_nn_ngraph_sim.py:58-96 (RHS), :168 (euler), :172-187 (head).
 #include "gnode_common.h"
 #include "gnode_h64.h"
 #include "gnode_mfma64.h"
 #include <algorithm>
-#include <cstdlib>
 
 template <bool NT>
 __device__ __forceinline__ float4 ld4so(const float* b, unsigned off) { return ld4s<NT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(b) + off)); }
 template <bool NT>
 __device__ __forceinline__ void st4so(float* b, unsigned off, float4 v) { st4s<NT>(reinterpret_cast<float*>(reinterpret_cast<char*>(b) + off), v); }
-
-// ---- pull-gather of one row by a 16-lane group ---------------------------------------
-// ascending-column accumulation order = the CPU scatter_add_ order of the reference.
-#ifndef GN_FWD_NB
-#define GN_FWD_NB 8          // neighbour rows in flight per lane group (4 -> 8: 379 -> 375 us per launch on the 75k graph x 8,
-                             // mid-size forwards -10 %; 16 would spill at 5 workgroups per CU)
-#endif
-__device__ __forceinline__ float4 gather_row64(const int* __restrict__ rowptr, const int* __restrict__ col,
-                                               const float* __restrict__ ZI_base, int node, bool valid, int sub) {
-    float4 acc = zero4();
-    int start = 0, end = 0;
-    if (valid) { start = rowptr[node]; end = rowptr[node + 1]; }
-    const unsigned lane_b = 16u * sub;
-    for (int e0 = start; e0 < end; e0 += 16) {
-        const int cnt = min(16, end - e0);
-        const unsigned mine = (sub < cnt) ? (unsigned)col[e0 + sub] * 256u : 0u;   // byte offset of the neighbour row
-#define GN_LD(K, V) float4 V = zero4(); if (K < cnt) V = ld4o(ZI_base, (unsigned)row_bcast<(K) & 15>((int)mine) + lane_b);
-#define GN_AC(V) acc.x += V.x; acc.y += V.y; acc.z += V.z; acc.w += V.w;
-#define GN_G4(J)                                                                               \
-        if (J < cnt) {                                                                         \
-            GN_LD(J, v0) GN_LD(J + 1, v1) GN_LD(J + 2, v2) GN_LD(J + 3, v3)                    \
-            GN_AC(v0) GN_AC(v1) GN_AC(v2) GN_AC(v3)                                            \
-        }
-#define GN_G8(J)                                                                               \
-        if (J < cnt) {                                                                         \
-            GN_LD(J, v0) GN_LD(J + 1, v1) GN_LD(J + 2, v2) GN_LD(J + 3, v3)                    \
-            GN_LD(J + 4, v4) GN_LD(J + 5, v5) GN_LD(J + 6, v6) GN_LD(J + 7, v7)                \
-            GN_AC(v0) GN_AC(v1) GN_AC(v2) GN_AC(v3) GN_AC(v4) GN_AC(v5) GN_AC(v6) GN_AC(v7)    \
-        }
-        if (GN_FWD_NB == 8) { GN_G8(0) GN_G8(8) } else { GN_G4(0) GN_G4(4) GN_G4(8) GN_G4(12) }
-#undef GN_G8
-#undef GN_G4
-#undef GN_AC
-#undef GN_LD
-    }
-    return acc;
-}
 
 // --------------------------------------------------------------------------- k_mlp64
 __global__ __launch_bounds__(256) void k_mlp64(const float* __restrict__ X, const float* __restrict__ W,
@@ -136,145 +94,293 @@ __device__ __forceinline__ void readout64(float4 yS, float4 yI, float4 yR, const
     pS = eS * inv; pI = eI * inv; pR = eR * inv;
 }
 
-#ifndef GN_RPG1_OCC
-#define GN_RPG1_OCC 5
+// --------------------------------------------------------------------------- k_step64: software-pipelined Euler step
+// Round 1's kernel walked a tile as a chain of five DEPENDENT memory round trips (Y_S row -> rowptr -> column ids ->
+// neighbour rows 0..7 -> 8..15) behind five barriers with nothing of the next tile in flight (SQ_WAIT_ANY 66 % of wave
+// cycles; 377 us per launch on the 75k graph x 8).  Here every workgroup keeps three tiles in flight (358 us):
+//     tile t    gather being summed, SIR update, read-out                       (stages A, B)
+//     tile t+1  Y_S row in registers -> LDS, first 8 neighbour rows + own rows requested   (stages B, C)
+//     tile t+2  rowptr / hub index / Y_S row / column ids requested             (top, D, F)
+// and the two node MLPs that used to be separate barrier-fenced phases -- Z_I'(t) from the updated Y_I rows and
+// Z_S(t+1) from the next tile's Y_S rows -- run in ONE matrix phase off one staged copy of W (each B fragment read
+// once for both), between the only two barriers of the iteration.  The neighbour rows of tile t+1 travel under that
+// matrix phase; the one exposed round trip per tile is the second half of the gather (8 loads in flight per lane group
+// is the register budget), covered by the other three workgroups of the CU.
+// Neighbour k of a row: lane (k & 15) of the 16-lane group holds its table byte offset in m (or the offset of the
+// table's ZERO ROW when the row has fewer neighbours), so every load is unconditional: no compare, no exec-mask
+// branch per neighbour, and hipcc counts the loads for its own s_waitcnt placement.
+template <int K>
+__device__ __forceinline__ float4 gat_ld(const float* __restrict__ ZI, unsigned m, unsigned lane_b) {
+    return ld4o(ZI, (unsigned)row_bcast<K & 15>((int)m) + lane_b);
+}
+#define GP_ACC(V) acc.x += V.x; acc.y += V.y; acc.z += V.z; acc.w += V.w;
+#define GP_SB __builtin_amdgcn_sched_barrier(0);
+
+// 16-row dual node MLP: OA = sigmoid(XA W^T + b), OB = sigmoid(XB W^T + b); per output the same two accumulation chains
+// (even / odd k-quads) as mfma_tile16, so the results are bit-identical to two separate calls.  All LDS addresses are
+// ONE per-lane offset plus compile-time constants (they fold into the DS instructions' offset fields).
+//   fo = (i*TS + 16*kq) floats: fragment offset inside a tile or inside W's 16-row slab;  oo = (4*kq*TS + i): result offset
+template <bool DO_A, bool DO_B>
+__device__ __forceinline__ void mfma_dual16(const float* __restrict__ XA, const float* __restrict__ XB,
+                                            const float* __restrict__ Wslab, float* __restrict__ OA,
+                                            float* __restrict__ OB, float bias_l, int fo, int oo) {
+    f32x4 a0 = {bias_l, bias_l, bias_l, bias_l}, a1 = {0.f, 0.f, 0.f, 0.f}, c0 = a0, c1 = a1;
+    // one k-quad of fragments at a time (12 registers): chain 0 takes the even quads, chain 1 the odd ones, each in
+    // the order mfma_tile16 feeds them; the A and B streams alternate, so a chain's next MFMA is two issue slots away
+#define GN_MQ(M, ACA, ACB) {                                                                                   \
+        const float4 wv = *reinterpret_cast<const float4*>(Wslab + fo + 4 * (M));                              \
+        float4 xa, xb;                                                                                         \
+        if (DO_A) xa = *reinterpret_cast<const float4*>(XA + fo + 4 * (M));                                    \
+        if (DO_B) xb = *reinterpret_cast<const float4*>(XB + fo + 4 * (M));                                    \
+        if (DO_A) ACA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wv.x, ACA, 0, 0, 0);                        \
+        if (DO_B) ACB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb.x, wv.x, ACB, 0, 0, 0);                        \
+        if (DO_A) ACA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wv.y, ACA, 0, 0, 0);                        \
+        if (DO_B) ACB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb.y, wv.y, ACB, 0, 0, 0);                        \
+        if (DO_A) ACA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wv.z, ACA, 0, 0, 0);                        \
+        if (DO_B) ACB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb.z, wv.z, ACB, 0, 0, 0);                        \
+        if (DO_A) ACA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wv.w, ACA, 0, 0, 0);                        \
+        if (DO_B) ACB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb.w, wv.w, ACB, 0, 0, 0); }
+    GN_MQ(0, a0, c0) GN_MQ(1, a1, c1) GN_MQ(2, a0, c0) GN_MQ(3, a1, c1)
+#undef GN_MQ
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (DO_A) OA[oo + r * TS] = sigmoid_f(a0[r] + a1[r]);
+        if (DO_B) OB[oo + r * TS] = sigmoid_f(c0[r] + c1[r]);
+    }
+}
+
+#ifndef GN_STEP_OCC
+#define GN_STEP_OCC 4
 #endif
-// RPG = rows per 16-lane group and tile: 2 -> 32-row tiles, 4 workgroups per CU; 1 (default) -> 16-row tiles: half
-// the LDS, the two row gathers of a lane group no longer run back to back, and no spills at 5 workgroups per CU.
-// Measured per launch, 75k graph x 8 samples: RPG=2 406 us; RPG=1 at 3/4/5/6/8 workgroups per CU 457/403/380/389/417 us;
-// one sample (latency-bound): 67 -> 59 us, fb-social-size graph (60 tiles): 12.6 -> 8.3 us per step.
-template <bool FUSE, bool PRJ, int RPG>
-__global__ __launch_bounds__(256, (RPG == 2 ? 4 : GN_RPG1_OCC)) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
-                                                long rows, int tiles_per_sample, long total_tiles,
-                                                float* Y, const float* __restrict__ ZI,
-                                                float* __restrict__ ZI_next, const float* __restrict__ W,
-                                                const float* __restrict__ bias, const float* __restrict__ beta,
-                                                const float* __restrict__ gamma, float dt,
-                                                const float* __restrict__ w3, const float* __restrict__ b3,
-                                                const float* __restrict__ w2, const float* __restrict__ b2,
-                                                float* __restrict__ PR, Step64Out out,
-                                                const int* __restrict__ hubidx, const float* __restrict__ AIhub, int n_hub) {
-    // measured on the 75k-node benchmark and fixed: non-temporal streaming state accesses (+4.2 %: the gather
-    // table keeps the L2) and 8 XCD-affine tile queues (+0.7 %)
+template <bool PRJ>
+__global__ __launch_bounds__(256, GN_STEP_OCC) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+                                                 long rows, int tiles_per_sample, long total_tiles,
+                                                 float* Y, const float* __restrict__ ZI,
+                                                 float* __restrict__ ZI_next, const float* __restrict__ W,
+                                                 const float* __restrict__ bias, const float* __restrict__ beta,
+                                                 const float* __restrict__ gamma, float dt,
+                                                 const float* __restrict__ w3, const float* __restrict__ b3,
+                                                 const float* __restrict__ w2, const float* __restrict__ b2,
+                                                 float* __restrict__ PR, Step64Out out,
+                                                 const int* __restrict__ hubidx, const float* __restrict__ AIhub, int n_hub) {
+    // measured on the 75k-node benchmark and fixed: non-temporal streaming state accesses (the gather table keeps the
+    // L2) and 8 XCD-affine tile queues.  (Write-through `sc1` state stores, which drop the line from L2: 366 vs 360 us.)
     constexpr bool NT = true;
     constexpr int XQ = 8;
-    __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
-    constexpr int TR = 16 * RPG;                  // rows per tile
-    __shared__ __attribute__((aligned(16))) float T[TR * TS];
-    __shared__ __attribute__((aligned(16))) float T2[TR * TS];
+    // one LDS block, sub-arrays at compile-time offsets: every access below is (one per-lane offset) + constant
+    constexpr int O_W = 0, O_TA = O_W + 64 * TS, O_TB = O_TA + 16 * TS, O_T2I = O_TB + 16 * TS, O_T2S = O_T2I + 16 * TS,
+                  O_W3 = O_T2S + 16 * TS, O_END = O_W3 + 4 * 64;
+    __shared__ __attribute__((aligned(16))) float L[O_END];
+    //   TA  updated Y_I rows of tile t (MFMA operand)     TB  Y_S rows of tile t+1 (MFMA operand)
+    //   T2I Z_I'(t)     T2S Z_S(t+1)     W3 read-out weight rows (re-read every tile: 16 loop-invariant VGPRs otherwise)
+    // (Measured and dropped: RECOMPUTING the row's own Z_I from its Y_I row in the same matrix phase instead of
+    //  reading it back -- 6 % fewer bytes through the L1-miss path, 44.5 KB of LDS, three workgroups per CU: 367 us
+    //  against 360 us per launch on the 75k graph x 8.)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
-    load_W_to_lds<false>(W, Wl);
-    const float bias_l = bias[16 * w + (lane & 15)];
+    load_W_to_lds<false>(W, L + O_W);
+    L[O_W3 + threadIdx.x] = w3[threadIdx.x];
+    float bias_l = bias[16 * w + (lane & 15)];
     const size_t slab = (size_t)rows * 64;
-    // state in / state out: in place (inference), or trajectory point k -> k+1 when the caller keeps `sol`
-    // (then the trajectory IS the state and nothing is written twice)
     const float* YS = Y; const float* YI = Y + slab; const float* YR = Y + 2 * slab;
     float* Yo = out.sol ? out.sol : Y;
     float* YSo = Yo; float* YIo = Yo + slab; float* YRo = Yo + 2 * slab;
+    const int lr = 4 * w + g;
+    const unsigned lane_b = 16u * sub;
+    int ro = lr * TS + 4 * sub;                            // this lane's 16 B of its row inside a tile
+    int fo = (lane & 15) * TS + 16 * (lane >> 4);          // MFMA fragment offset (tile row i, k-quarter kq)
+    int oo = 4 * (lane >> 4) * TS + 16 * w + (lane & 15);  // MFMA result offset (rows 4kq.., column 16w + i)
 
-    int lr[RPG];
-#pragma unroll
-    for (int p = 0; p < RPG; ++p) lr[p] = w * 4 * RPG + 4 * p + g;
-
-    // Tile walk.  XQ > 1: the tile range is cut into XQ contiguous queues (with 8 samples per launch a queue
-    // is one sample) and workgroup i serves queue i % XQ.  Workgroups are dealt round-robin over the 8 XCDs,
-    // so queue q is gathered through ONE XCD's L2: a sample's Z_I table competes for 4 MB instead of being
-    // spread over all eight L2s.  Placement only affects speed: every tile is visited exactly once either way.
+    // Tile walk: the tile range is cut into XQ contiguous queues (with 8 samples per launch a queue is one sample) and
+    // workgroup i serves queue i % XQ.  Workgroups are dealt round-robin over the 8 XCDs, so queue q is gathered through
+    // ONE XCD's L2: a sample's Z_I table competes for 4 MB instead of being spread over all eight L2s (speed only: every
+    // tile is visited exactly once either way).  Everything here is uniform and
+    // 32-bit (the launcher bounds rows < 2^24, so tiles < 2^20); readfirstlane pins the values to SGPRs -- left to
+    // itself the compiler kept the 64-bit queue end in VGPRs, spilled it, and the reload's s_waitcnt vmcnt(0) at the
+    // top of every iteration drained the whole prefetch pipeline.
     const int xq = (XQ > 1 && gridDim.x % XQ == 0 && total_tiles >= 4 * XQ) ? XQ : 1;
     const int q = blockIdx.x % xq;
-    const long q_lo = total_tiles * q / xq, q_hi = total_tiles * (q + 1) / xq;
-    // (sample, tile) advance incrementally: no 64-bit division in the tile loop
-    const long t_first = q_lo + blockIdx.x / xq;
-    long b = t_first / tiles_per_sample;
-    int tile = (int)(t_first - b * tiles_per_sample);
+    const int q_lo = __builtin_amdgcn_readfirstlane((int)(total_tiles * q / xq));
+    const int q_hi = __builtin_amdgcn_readfirstlane((int)(total_tiles * (q + 1) / xq));
     const int t_stride = gridDim.x / xq;
-    for (long t = t_first; t < q_hi; t += t_stride, tile += t_stride) {
-        while (tile >= tiles_per_sample) { tile -= tiles_per_sample; ++b; }
-        const long base = b * n;
-        int node[RPG]; bool valid[RPG]; unsigned off[RPG];       // off: BYTE offset of this lane's 16 B inside a slab
-        float4 ys[RPG], ai[RPG], yi[RPG], yr[RPG], zi[RPG];
-#pragma unroll
-        for (int p = 0; p < RPG; ++p) {
-            node[p] = tile * TR + lr[p];
-            valid[p] = node[p] < n;
-            off[p] = (unsigned)(base + node[p]) * 256u + 16u * sub;
-            ys[p] = valid[p] ? ld4so<NT>(YS, off[p]) : zero4();
+    int t_it = q_lo + blockIdx.x / xq;                     // iterator: the tile the NEXT fetch_head() describes
+    int b_it = __builtin_amdgcn_readfirstlane(t_it / tiles_per_sample);
+    int tile_it = t_it - b_it * tiles_per_sample;
+
+    // ---- per-stage state.  Uniform across the workgroup: *_ok (tile inside the queue).  Per lane group: the row.
+    struct Stage { bool ok; bool valid; bool hub; unsigned row, base; int start, end; unsigned mine, mine2, hoff; };
+    const unsigned zoff = (unsigned)rows * 256u;           // byte offset of the table's zero row (one past the last row)
+    auto fetch_head = [&](Stage& s) {                      // top of the chain: row id, rowptr, hub index (loads unconditional)
+        s.ok = t_it < q_hi;
+        while (tile_it >= tiles_per_sample) { tile_it -= tiles_per_sample; ++b_it; }
+        const int node = tile_it * 16 + lr;
+        s.valid = s.ok && node < n;
+        const int nodec = s.valid ? node : 0;
+        s.row = s.valid ? (unsigned)b_it * (unsigned)n + (unsigned)node : 0u;
+        s.start = rowptr[nodec]; s.end = rowptr[nodec + 1];
+        s.hub = false; s.mine = 0u; s.hoff = 0u;
+        if (hubidx) {                                      // uniform: graphs without long rows skip all of this
+            const int h = hubidx[nodec];
+            s.hub = s.valid && h >= 0;
+            s.hoff = s.hub ? ((unsigned)b_it * (unsigned)n_hub + (unsigned)h) * 256u : 0u;
         }
-        // -------- P1: stage Y_S, issue own-row loads, gather
-#pragma unroll
-        for (int p = 0; p < RPG; ++p) {
-            *reinterpret_cast<float4*>(T + lr[p] * TS + 4 * sub) = ys[p];
-            yi[p] = valid[p] ? ld4so<NT>(YI, off[p]) : zero4();
-            yr[p] = (!PRJ && valid[p]) ? ld4so<NT>(YR, off[p]) : zero4();
-            zi[p] = valid[p] ? ld4o(ZI, off[p]) : zero4();
+        if (!s.valid) s.end = s.start;
+        s.base = (unsigned)b_it * (unsigned)n;             // first row of the tile's sample (uniform)
+        t_it += t_stride; tile_it += t_stride;
+    };
+    auto fetch_cols = [&](Stage& s) {                      // second link: the first 32 column ids as table byte offsets
+        const unsigned base = s.base;
+        const int d = s.hub ? 0 : s.end - s.start;
+        const int c0 = col[sub < d ? s.start + sub : 0], c1 = col[16 + sub < d ? s.start + 16 + sub : 0];
+        s.mine = sub < d ? (base + (unsigned)c0) * 256u : zoff;
+        s.mine2 = 16 + sub < d ? (base + (unsigned)c1) * 256u : zoff;
+        if (s.hub) s.end = s.start;                        // nothing to gather: the sum arrives from the hub kernels
+    };
+
+    Stage cur, n1, n2;
+    cur.ok = false; cur.valid = false; cur.hub = false; cur.row = 0; cur.start = cur.end = 0; cur.mine = cur.mine2 = zoff; cur.hoff = 0; cur.base = 0;
+    fetch_head(n1);
+    float4 ys_n1 = ld4so<NT>(YS, n1.row * 256u + lane_b);
+    fetch_cols(n1);
+    float4 v0 = zero4(), v1 = zero4(), v2 = zero4(), v3 = zero4(), v4 = zero4(), v5 = zero4(), v6 = zero4(), v7 = zero4();
+    float4 yi = zero4(), yr = zero4(), zi = zero4(), pr = zero4();
+    float nb = 0.f, gm = 0.f;
+    __syncthreads();                                       // W staged
+
+    for (;;) {
+        // keep the LDS offsets opaque per iteration: hoisted out of the loop, every (offset + constant) becomes its own
+        // loop-invariant VGPR (a dozen of them) instead of an instruction offset field
+        asm volatile("" : "+v"(ro), "+v"(fo), "+v"(oo), "+v"(bias_l));
+        float* const tA = L + O_TA + ro;
+        float* const tB = L + O_TB + ro;
+        const float* const t2i = L + O_T2I + ro;
+        const float* const t2s = L + O_T2S + ro;
+        const float* const w3s = L + O_W3;
+        // ---- top: head of tile t+2's chain
+        fetch_head(n2);
+        // ---- A: finish the gather of tile t.  v0..v7 hold neighbours 0..7 (requested one matrix phase ago); further
+        // neighbours roll through the same eight registers four at a time, as far as the longest row of the WAVE needs
+        // (wave-uniform branches), always summed in ascending column order (the CPU scatter_add_ order of the reference).
+        float4 acc = zero4();
+        {
+            const int cnt = cur.hub ? 0 : cur.end - cur.start;
+            const unsigned m = cur.mine, m2 = cur.mine2;
+#define GP_R(V, K) GP_ACC(V) V = gat_ld<K>(ZI, (K) < 16 ? mm : mm2, lane_b); GP_SB
+#define GP_RA(K) GP_R(v0, K) GP_R(v1, (K) + 1) GP_R(v2, (K) + 2) GP_R(v3, (K) + 3)
+#define GP_RB(K) GP_R(v4, K) GP_R(v5, (K) + 1) GP_R(v6, (K) + 2) GP_R(v7, (K) + 3)
+#define GP_FA GP_ACC(v0) GP_ACC(v1) GP_ACC(v2) GP_ACC(v3) GP_ACC(v4) GP_ACC(v5) GP_ACC(v6) GP_ACC(v7)
+#define GP_FB GP_ACC(v4) GP_ACC(v5) GP_ACC(v6) GP_ACC(v7) GP_ACC(v0) GP_ACC(v1) GP_ACC(v2) GP_ACC(v3)
+            // one straight-line path per gather length (wave-uniform switch): only `acc` is live at the join, so the eight
+            // row registers never meet in a phi and stay eight registers
+            const int nb4 = (__any(cnt > 8) ? 1 : 0) + (__any(cnt > 12) ? 1 : 0) + (__any(cnt > 16) ? 1 : 0) +
+                            (__any(cnt > 20) ? 1 : 0) + (__any(cnt > 24) ? 1 : 0) + (__any(cnt > 28) ? 1 : 0);
+            // (GP_OPQ: a per-case opaque copy of the offsets -- otherwise the 24 broadcast addresses are hoisted above the
+            //  switch as common subexpressions, 24 live VGPRs and a spill whose reload drains every load in flight)
+#define GP_OPQ unsigned mm = m, mm2 = m2; asm volatile("" : "+v"(mm), "+v"(mm2));
+            switch (nb4) {
+                case 0: { GP_FA } break;
+                case 1: { GP_OPQ GP_RA(8) GP_FB } break;
+                case 2: { GP_OPQ GP_RA(8) GP_RB(12) GP_FA } break;
+                case 3: { GP_OPQ GP_RA(8) GP_RB(12) GP_RA(16) GP_FB } break;
+                case 4: { GP_OPQ GP_RA(8) GP_RB(12) GP_RA(16) GP_RB(20) GP_FA } break;
+                case 5: { GP_OPQ GP_RA(8) GP_RB(12) GP_RA(16) GP_RB(20) GP_RA(24) GP_FB } break;
+                default: { GP_OPQ GP_RA(8) GP_RB(12) GP_RA(16) GP_RB(20) GP_RA(24) GP_RB(28) GP_FA } break;
+            }
+#undef GP_OPQ
+#undef GP_FB
+#undef GP_FA
+#undef GP_RB
+#undef GP_RA
+#undef GP_R
+            // rows of 33 .. hub-threshold edges: the plain chunked walk for the rest
+            if (__any(cnt > 32)) {
+                const unsigned base = cur.base;
+                for (int e0 = cur.start + 32; e0 < cur.end; e0 += 16) {
+                    const int c2 = cur.end - e0;
+                    const unsigned mm = (sub < c2) ? (base + (unsigned)col[e0 + sub]) * 256u : zoff;
+                    {
+                        float4 u0 = gat_ld<0>(ZI, mm, lane_b), u1 = gat_ld<1>(ZI, mm, lane_b), u2 = gat_ld<2>(ZI, mm, lane_b), u3 = gat_ld<3>(ZI, mm, lane_b);
+                        float4 u4 = gat_ld<4>(ZI, mm, lane_b), u5 = gat_ld<5>(ZI, mm, lane_b), u6 = gat_ld<6>(ZI, mm, lane_b), u7 = gat_ld<7>(ZI, mm, lane_b);
+                        GP_ACC(u0) GP_ACC(u1) GP_ACC(u2) GP_ACC(u3) GP_ACC(u4) GP_ACC(u5) GP_ACC(u6) GP_ACC(u7)
+                    }
+                    if (c2 > 8) {
+                        float4 u0 = gat_ld<8>(ZI, mm, lane_b), u1 = gat_ld<9>(ZI, mm, lane_b), u2 = gat_ld<10>(ZI, mm, lane_b), u3 = gat_ld<11>(ZI, mm, lane_b);
+                        float4 u4 = gat_ld<12>(ZI, mm, lane_b), u5 = gat_ld<13>(ZI, mm, lane_b), u6 = gat_ld<14>(ZI, mm, lane_b), u7 = gat_ld<15>(ZI, mm, lane_b);
+                        GP_ACC(u0) GP_ACC(u1) GP_ACC(u2) GP_ACC(u3) GP_ACC(u4) GP_ACC(u5) GP_ACC(u6) GP_ACC(u7)
+                    }
+                }
+            }
         }
-        // (measured: gathering the two rows in lockstep with 8 loads in flight per lane is 25 % SLOWER --
-        //  the memory system is already at its request-rate limit)
-        // long rows ("hubs") were summed beforehand by the segment kernels of gnode_hub.hip
-#pragma unroll
-        for (int p = 0; p < RPG; ++p) {
-            const int hub = (hubidx && valid[p]) ? hubidx[node[p]] : -1;
-            if (hub >= 0) ai[p] = ld4o(AIhub, ((unsigned)b * (unsigned)n_hub + (unsigned)hub) * 256u + 16u * sub);
-            else ai[p] = gather_row64(rowptr, col, ZI + (size_t)base * 64, node[p], valid[p], sub);
-        }
-        __syncthreads();
-        // -------- P2: Z_S on the matrix cores
-        if (RPG == 2) mfma_tile<true>(T, Wl, T2, bias_l, w, lane); else mfma_tile16<true>(T, Wl, T2, bias_l, w, lane);
-        __syncthreads();
-        // -------- P3: SIR derivative (ode_nn_ngraph_sim.py:75-77), Euler update, read-out
-#pragma unroll
-        for (int p = 0; p < RPG; ++p) {
-            const float4 zs = *reinterpret_cast<const float4*>(T2 + lr[p] * TS + 4 * sub);
-            float nb = 0.f, gm = 0.f;
-            if (valid[p]) { nb = -beta[base + node[p]]; gm = gamma[base + node[p]]; }
+        // ---- B: P3 of tile t (ode_nn_ngraph_sim.py:75-77, Euler update, read-out), then stage the MFMA operands
+        if (cur.ok) {
+            const unsigned off = cur.row * 256u + lane_b;
+            const float4 zs = *reinterpret_cast<const float4*>(t2s);
+            float4 ys = *reinterpret_cast<const float4*>(tB);          // this row's Y_S, staged one iteration ago
             float4 dS, dI, dR;
-            dS.x = nb * (ai[p].x * zs.x); dS.y = nb * (ai[p].y * zs.y); dS.z = nb * (ai[p].z * zs.z); dS.w = nb * (ai[p].w * zs.w);
-            dR.x = gm * zi[p].x; dR.y = gm * zi[p].y; dR.z = gm * zi[p].z; dR.w = gm * zi[p].w;
+            dS.x = nb * (acc.x * zs.x); dS.y = nb * (acc.y * zs.y); dS.z = nb * (acc.z * zs.z); dS.w = nb * (acc.w * zs.w);
+            dR.x = gm * zi.x; dR.y = gm * zi.y; dR.z = gm * zi.z; dR.w = gm * zi.w;
             dI.x = -dS.x - dR.x; dI.y = -dS.y - dR.y; dI.z = -dS.z - dR.z; dI.w = -dS.w - dR.w;
-            ys[p].x += dt * dS.x; ys[p].y += dt * dS.y; ys[p].z += dt * dS.z; ys[p].w += dt * dS.w;
-            yi[p].x += dt * dI.x; yi[p].y += dt * dI.y; yi[p].z += dt * dI.z; yi[p].w += dt * dI.w;
+            ys.x += dt * dS.x; ys.y += dt * dS.y; ys.z += dt * dS.z; ys.w += dt * dS.w;
+            yi.x += dt * dI.x; yi.y += dt * dI.y; yi.z += dt * dI.z; yi.w += dt * dI.w;
             float prj[4] = {0.f, 0.f, 0.f, 0.f};
             if (PRJ) {
-                // R only feeds the read-out, and its first layer is linear: carry w3 . Y_R (4 floats per row)
-                // instead of Y_R (64):  w3 . (Y_R + dt*gamma*Z_I) = w3 . Y_R + dt*gamma*(w3 . Z_I)
-                float4 pr = zero4();
-                if (valid[p]) pr = ld4o(PR, (unsigned)(base + node[p]) * 16u);
                 float4 w3r[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) w3r[k] = ld4g(w3 + k * 64 + 4 * sub);   // L1-resident, shared with the read-out
-                prj[0] = pr.x + dt * (gm * row_sum16(fmaf(w3r[0].x, zi[p].x, fmaf(w3r[0].y, zi[p].y, fmaf(w3r[0].z, zi[p].z, w3r[0].w * zi[p].w)))));
-                prj[1] = pr.y + dt * (gm * row_sum16(fmaf(w3r[1].x, zi[p].x, fmaf(w3r[1].y, zi[p].y, fmaf(w3r[1].z, zi[p].z, w3r[1].w * zi[p].w)))));
-                prj[2] = pr.z + dt * (gm * row_sum16(fmaf(w3r[2].x, zi[p].x, fmaf(w3r[2].y, zi[p].y, fmaf(w3r[2].z, zi[p].z, w3r[2].w * zi[p].w)))));
-                prj[3] = pr.w + dt * (gm * row_sum16(fmaf(w3r[3].x, zi[p].x, fmaf(w3r[3].y, zi[p].y, fmaf(w3r[3].z, zi[p].z, w3r[3].w * zi[p].w)))));
-                if (valid[p] && sub == 0) st4o(PR, (unsigned)(base + node[p]) * 16u, make_float4(prj[0], prj[1], prj[2], prj[3]));
+                for (int k = 0; k < 4; ++k) w3r[k] = *reinterpret_cast<const float4*>(w3s + k * 64 + 4 * sub);
+                prj[0] = pr.x + dt * (gm * row_sum16(fmaf(w3r[0].x, zi.x, fmaf(w3r[0].y, zi.y, fmaf(w3r[0].z, zi.z, w3r[0].w * zi.w)))));
+                prj[1] = pr.y + dt * (gm * row_sum16(fmaf(w3r[1].x, zi.x, fmaf(w3r[1].y, zi.y, fmaf(w3r[1].z, zi.z, w3r[1].w * zi.w)))));
+                prj[2] = pr.z + dt * (gm * row_sum16(fmaf(w3r[2].x, zi.x, fmaf(w3r[2].y, zi.y, fmaf(w3r[2].z, zi.z, w3r[2].w * zi.w)))));
+                prj[3] = pr.w + dt * (gm * row_sum16(fmaf(w3r[3].x, zi.x, fmaf(w3r[3].y, zi.y, fmaf(w3r[3].z, zi.z, w3r[3].w * zi.w)))));
+                if (cur.valid && sub == 0) st4o(PR, cur.row * 16u, make_float4(prj[0], prj[1], prj[2], prj[3]));
             } else {
-                yr[p].x += dt * dR.x; yr[p].y += dt * dR.y; yr[p].z += dt * dR.z; yr[p].w += dt * dR.w;
+                yr.x += dt * dR.x; yr.y += dt * dR.y; yr.z += dt * dR.z; yr.w += dt * dR.w;
             }
-            if (valid[p]) {
-                st4so<NT>(YSo, off[p], ys[p]); st4so<NT>(YIo, off[p], yi[p]);
-                if (!PRJ) st4so<NT>(YRo, off[p], yr[p]);
+            if (cur.valid) {
+                st4so<NT>(YSo, off, ys); st4so<NT>(YIo, off, yi);
+                if (!PRJ) st4so<NT>(YRo, off, yr);
             }
             if (out.S) {
                 float pS, pI, pR;
-                readout64<PRJ>(ys[p], yi[p], yr[p], prj, sub, w3, b3, w2, b2, pS, pI, pR);
-                if (valid[p] && sub == 0) {
-                    out.S[base + node[p]] = pS; out.I[base + node[p]] = pI; out.R[base + node[p]] = pR;
-                }
+                readout64<PRJ>(ys, yi, yr, prj, sub, w3s, b3, w2, b2, pS, pI, pR);
+                if (cur.valid && sub == 0) { out.S[cur.row] = pS; out.I[cur.row] = pI; out.R[cur.row] = pR; }
             }
-            if (FUSE) *reinterpret_cast<float4*>(T + lr[p] * TS + 4 * sub) = yi[p];   // stage Y_I' for P4
+            *reinterpret_cast<float4*>(tA) = yi;                       // Y_I' -> operand of Z_I'(t)
         }
-        if (FUSE) {
-            // -------- P4: Z_I of the next step from the updated Y_I rows
-            __syncthreads();
-            if (RPG == 2) mfma_tile<true>(T, Wl, T2, bias_l, w, lane); else mfma_tile16<true>(T, Wl, T2, bias_l, w, lane);
-            __syncthreads();
-#pragma unroll
-            for (int p = 0; p < RPG; ++p)
-                if (valid[p]) st4o(ZI_next, off[p], *reinterpret_cast<const float4*>(T2 + lr[p] * TS + 4 * sub));
+        if (n1.ok) *reinterpret_cast<float4*>(tB) = ys_n1;             // Y_S(t+1) -> operand of Z_S(t+1)
+        // ---- C: request tile t+1's first 8 neighbour rows and its own rows (they travel under the matrix phase)
+        {
+            const unsigned m = n1.mine;
+            v0 = gat_ld<0>(ZI, m, lane_b); v1 = gat_ld<1>(ZI, m, lane_b); v2 = gat_ld<2>(ZI, m, lane_b); v3 = gat_ld<3>(ZI, m, lane_b);
+            v4 = gat_ld<4>(ZI, m, lane_b); v5 = gat_ld<5>(ZI, m, lane_b); v6 = gat_ld<6>(ZI, m, lane_b); v7 = gat_ld<7>(ZI, m, lane_b);
+            if (hubidx) {                                              // hub rows: the whole sum arrives pre-reduced
+                const float4 h = ld4o(AIhub, n1.hoff + lane_b);
+                if (n1.hub) v0 = h;
+            }
+            const unsigned off = n1.row * 256u + lane_b;
+            yi = ld4so<NT>(YI, off);
+            if (!PRJ) yr = ld4so<NT>(YR, off);
+            zi = ld4o(ZI, off);
+            if (PRJ) pr = ld4o(PR, n1.row * 16u);
+            nb = -beta[n1.row]; gm = gamma[n1.row];
         }
-        __syncthreads();   // T / T2 are rewritten by the next tile
+        // ---- D: tile t+2's Y_S row
+        const float4 ys_n2 = ld4so<NT>(YS, n2.row * 256u + lane_b);
+        __syncthreads();
+        // ---- E: Z_I'(t) and Z_S(t+1) in one matrix phase, each W fragment read once for both
+#define GN_DUAL(A, B) mfma_dual16<A, B>(L + O_TA, L + O_TB, L + O_W + 16 * w * TS, L + O_T2I, L + O_T2S, bias_l, fo, oo)
+        if (cur.ok && n1.ok) GN_DUAL(true, true);
+        else if (cur.ok) GN_DUAL(true, false);
+        else if (n1.ok) GN_DUAL(false, true);
+#undef GN_DUAL
+        __syncthreads();
+        // ---- F: next step's gather table row of tile t; column ids of tile t+2
+        if (cur.valid) st4o(ZI_next, cur.row * 256u + lane_b, *reinterpret_cast<const float4*>(t2i));
+        fetch_cols(n2);
+        if (!n1.ok) break;
+        cur = n1; n1 = n2; ys_n1 = ys_n2;
     }
 }
+#undef GP_SB
+#undef GP_ACC
 
 // --------------------------------------------------------------------------- k_tiny64: whole integration in ONE launch
 // Graphs whose per-sample state fits a workgroup's LDS (n <= 96 nodes at H = 64: karate, dolphins -- the
@@ -440,8 +546,7 @@ size_t gn_tiny64_lds_bytes(int n, bool prj) {
 
 // true when the whole integration of one sample fits a workgroup (and the schedule fits the kernel arguments)
 bool gn_tiny64_ok(int n, int n_steps, int n_out, bool prj) {
-    static const bool on = [] { const char* e = getenv("GNODE_TINY"); return !(e && e[0] == '0'); }();
-    return on && n_steps >= 1 && n_steps <= 128 && n_out < 32768 && n <= 3 * TILE_ROWS &&
+    return n_steps >= 1 && n_steps <= 128 && n_out < 32768 && n <= 3 * TILE_ROWS &&
            gn_tiny64_lds_bytes(n, prj) <= 160 * 1024;
 }
 
@@ -456,13 +561,9 @@ int gn_launch_tiny64(const gnode_graph_s* g, long rows, const float* Y0, const f
     const unsigned B = (unsigned)(rows / g->n);
     const unsigned threads = 256u * (unsigned)((g->n + TILE_ROWS - 1) / TILE_ROWS);
     if (prj) {
-        static bool attr = false;
-        if (!attr) { GN_HIP(hipFuncSetAttribute((const void*)k_tiny64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
         hipLaunchKernelGGL(k_tiny64<true>, dim3(B), dim3(threads), lds, st, g->rowptr, g->col, g->n, rows, Y0, ZI0, PR0, W, bias, beta,
                            gamma, sched, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, S, I, R, sol);
     } else {
-        static bool attr = false;
-        if (!attr) { GN_HIP(hipFuncSetAttribute((const void*)k_tiny64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
         hipLaunchKernelGGL(k_tiny64<false>, dim3(B), dim3(threads), lds, st, g->rowptr, g->col, g->n, rows, Y0, ZI0, PR0, W, bias, beta,
                            gamma, sched, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, S, I, R, sol);
     }
@@ -480,9 +581,14 @@ __global__ __launch_bounds__(256) void k_prologue64(const float* __restrict__ x,
                                                     const float* __restrict__ b3, const float* __restrict__ w2,
                                                     const float* __restrict__ b2, float* __restrict__ Y,
                                                     float* __restrict__ beta, float* __restrict__ gamma,
-                                                    float* __restrict__ sol0, float* __restrict__ ZI, float* __restrict__ PR,
+                                                    float* __restrict__ sol0, float* __restrict__ ZI, float* __restrict__ ZI_alt,
+                                                    float* __restrict__ PR,
                                                     float* __restrict__ S0, float* __restrict__ I0, float* __restrict__ R0,
                                                     long rows) {
+    if (blockIdx.x == 0 && threadIdx.x < 32) {            // the zero rows behind the two gather tables (k_step64p)
+        float* z = (threadIdx.x < 16 ? ZI : ZI_alt) + (size_t)rows * 64 + 4 * (threadIdx.x & 15);
+        st4g(z, zero4());
+    }
     __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
     __shared__ __attribute__((aligned(16))) float T[TILE_ROWS * TS];
     __shared__ __attribute__((aligned(16))) float T2[TILE_ROWS * TS];
@@ -545,39 +651,27 @@ __global__ __launch_bounds__(256) void k_prologue64(const float* __restrict__ x,
 }
 
 int gn_launch_prologue64(const float* x, const gnode_params* p, float* Y, float* beta, float* gamma, float* sol0, float* ZI,
-                         float* PR, float* S0, float* I0, float* R0, long rows, hipStream_t st) {
+                         float* ZI_alt, float* PR, float* S0, float* I0, float* R0, long rows, hipStream_t st) {
     const long ntiles = (rows + TILE_ROWS - 1) / TILE_ROWS;
     hipLaunchKernelGGL(k_prologue64, dim3((unsigned)std::min<long>(ntiles, 2048)), dim3(256), 0, st, x, p->linearS1_weight,
                        p->linearS1_bias, p->odefunc_linear_weight, p->odefunc_linear_bias, p->linear3_weight, p->linear3_bias,
-                       p->linearS2_weight, p->linearS2_bias, Y, beta, gamma, sol0, ZI, PR, S0, I0, R0, rows);
+                       p->linearS2_weight, p->linearS2_bias, Y, beta, gamma, sol0, ZI, ZI_alt, PR, S0, I0, R0, rows);
     GN_LAUNCH_CHECK();
     return 0;
 }
 
 // --------------------------------------------------------------------------- host launchers
-// grid sizing knob for experiments: GNODE_WGS_PER_CU = k (persistent grid of k*CUs), 0 = one workgroup per tile
-static int wgs_per_cu() {
-    static const int v = [] { const char* e = getenv("GNODE_WGS_PER_CU"); return e ? atoi(e) : 4; }();
-    return v;
-}
-static int g_num_cu = 0;
-static int num_cus() {
-    if (g_num_cu == 0) {
-        int dev = 0, cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceProp_t p;
-            if (hipGetDeviceProperties(&p, dev) == hipSuccess) cu = p.multiProcessorCount;
-        }
-        g_num_cu = cu > 0 ? cu : 256;
-    }
-    return g_num_cu;
+int gn_h64_set_attributes() {
+    // dynamic LDS above 64 KB needs the attribute once per device: done at graph creation, never on a launch path
+    GN_HIP(hipFuncSetAttribute((const void*)k_tiny64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GN_HIP(hipFuncSetAttribute((const void*)k_tiny64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
 }
 
-int gn_launch_mlp64(const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st) {
+int gn_launch_mlp64(const gnode_graph_s* g, const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st) {
     if (nrows <= 0) return 0;
     const long ntiles = (nrows + TILE_ROWS - 1) / TILE_ROWS;
-    const int k = wgs_per_cu();
-    const int grid = (int)(k > 0 ? std::min<long>(ntiles, (long)num_cus() * k) : ntiles);
+    const int grid = (int)std::min<long>(ntiles, (long)g->num_cu * 4);
     hipLaunchKernelGGL(k_mlp64, dim3(grid), dim3(256), 0, st, X, W, b, Z, nrows);
     GN_LAUNCH_CHECK();
     return 0;
@@ -585,29 +679,23 @@ int gn_launch_mlp64(const float* X, const float* W, const float* b, float* Z, lo
 
 int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, float* ZI_next, const float* W,
                      const float* bias, const float* beta, const float* gamma, float dt, const gnode_params* p,
-                     float* PR, Step64Out out, bool fuse, hipStream_t st) {
+                     float* PR, Step64Out out, void* hub_scratch, hipStream_t st) {
     GN_CHECK_ARG(rows < (1L << 24), "H=64 step kernel addresses rows with 32-bit byte offsets: rows=%ld >= 2^24 per launch "
                  "(split the batch)", rows);
-    static const int rpg = [] { const char* e = getenv("GNODE_RPG"); return (e && e[0] == '2') ? 2 : 1; }();
-    const int tr = 16 * rpg;
-    const int tps = (g->n + tr - 1) / tr;
+    const int tps = (g->n + 15) / 16;
     const long total = (long)(rows / g->n) * tps;
     const float* AIhub = nullptr;
-    if (int e = gn_hub_gather(g, rows / g->n, 64, ZI, nullptr, &AIhub, nullptr, st)) return e;
-    const int k = wgs_per_cu() > 0 ? (rpg == 1 ? wgs_per_cu() * GN_RPG1_OCC / 4 : wgs_per_cu()) : 0;
-    // (measured: shrinking the grid so that every persistent workgroup gets the same number of tiles is 3 % SLOWER
-    //  than filling all 4 x CUs slots and accepting a +-1 tile imbalance -- residency matters more)
-    const int grid = (int)(k > 0 ? std::min<long>(total, (long)num_cus() * k) : total);
-    const bool prj = PR != nullptr;
-#define GN_STEP(F, P, Q)                                                                                                    \
-    hipLaunchKernelGGL((k_step64<F, P, Q>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, \
-                       ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,           \
-                       p->linearS2_bias, PR, out, g->hubidx, AIhub, g->n_hub)
-#define GN_STEP_Q(F, P) do { if (rpg == 1) GN_STEP(F, P, 1); else GN_STEP(F, P, 2); } while (0)
-    if (fuse) { if (prj) GN_STEP_Q(true, true); else GN_STEP_Q(true, false); }
-    else { if (prj) GN_STEP_Q(false, true); else GN_STEP_Q(false, false); }
-#undef GN_STEP_Q
-#undef GN_STEP
+    if (int e = gn_hub_gather(g, rows / g->n, 64, ZI, nullptr, hub_scratch, &AIhub, nullptr, st)) return e;
+    // persistent grid: GN_STEP_OCC workgroups per CU (measured: 3 / 4 / 5 per CU -> 363 / 360 / 400 us per launch on the
+    // 75k graph x 8; shrinking the grid so that every workgroup gets the same number of tiles is slower than filling
+    // every slot and accepting a +-1 tile imbalance)
+    const int grid = (int)std::min<long>(total, (long)g->num_cu * GN_STEP_OCC);
+    if (PR) hipLaunchKernelGGL(k_step64<true>, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, ZI_next, W,
+                               bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, PR,
+                               out, g->hubidx, AIhub, g->n_hub);
+    else hipLaunchKernelGGL(k_step64<false>, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, ZI_next, W,
+                            bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, PR,
+                            out, g->hubidx, AIhub, g->n_hub);
     GN_LAUNCH_CHECK();
     return 0;
 }

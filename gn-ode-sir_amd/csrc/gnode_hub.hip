@@ -18,19 +18,19 @@
 //
 // Deterministic (no atomics): a hub's sum is blocked by segment but always in the same order.
 // Up to two tables are reduced through the same index lists in one pass (the backward needs
-// A Z_I and A q).  Scratch lives in the graph handle and only ever grows, so after the first call
-// with a given batch size the launch path allocates nothing (hipGraph-capturable).
+// A Z_I and A q).  Segment partials and hub sums live in the CALLER's workspace
+// (gn_hub_scratch_bytes is part of gnode_{rhs,forward,backward}_workspace_bytes): the launch path
+// allocates nothing, synchronises nothing and keeps nothing in the handle, so it can be captured into a
+// hipGraph on first use and one handle serves several streams.
 #include "gnode_common.h"
 #include <algorithm>
-#include <cstdlib>
 #include <vector>
 
 #define HUB_SEG 32
 
-static int hub_threshold() {
-    static const int v = [] { const char* e = getenv("GNODE_HUB_T"); int t = e ? atoi(e) : 96; return t < 4 ? 4 : t; }();
-    return v;
-}
+#ifndef GN_HUB_T
+#define GN_HUB_T 96          // rows longer than this are hubs (measured break-even against the two extra launches per step)
+#endif
 
 __device__ __forceinline__ float4 hld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void hst4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_hub_reduce(const int* __restrict__ hub_
 
 // --------------------------------------------------------------------------- host: build + launch
 int gn_hub_build(gnode_graph_s* g, const int32_t* rowptr_host) {
-    const int T = hub_threshold();
+    const int T = GN_HUB_T;
     std::vector<int32_t> hubidx((size_t)g->n, -1), seg_lo, seg_hi, hub_seg_ptr(1, 0);
     int n_hub = 0;
     for (int32_t r = 0; r < g->n; ++r) {
@@ -134,8 +134,6 @@ int gn_hub_build(gnode_graph_s* g, const int32_t* rowptr_host) {
     g->n_hub = n_hub;
     g->n_seg = (int32_t)seg_lo.size();
     g->hubidx = g->seg_lo = g->seg_hi = g->hub_seg_ptr = nullptr;
-    g->hub_scratch = nullptr;
-    g->hub_scratch_bytes = 0;
     if (n_hub == 0) return 0;
     auto up = [](int32_t** dst, const std::vector<int32_t>& v) -> hipError_t {
         hipError_t e = hipMalloc(dst, sizeof(int32_t) * v.size());
@@ -154,7 +152,6 @@ void gn_hub_free(gnode_graph_s* g) {
     if (g->seg_lo) (void)hipFree(g->seg_lo);
     if (g->seg_hi) (void)hipFree(g->seg_hi);
     if (g->hub_seg_ptr) (void)hipFree(g->hub_seg_ptr);
-    if (g->hub_scratch) (void)hipFree(g->hub_scratch);
 }
 
 static int hub_lpr(int H) {
@@ -174,28 +171,27 @@ static int hub_lpr(int H) {
         default: { constexpr int LPR = 64; __VA_ARGS__; } break; \
     }
 
+size_t gn_hub_scratch_bytes(const gnode_graph_s* g, long B, int H, int ntables) {
+    if (g->n_hub == 0) return 0;
+    const size_t part_f = (size_t)B * g->n_seg * H, hub_f = (size_t)B * g->n_hub * H;
+    return (size_t)ntables * (gn_align(sizeof(float) * part_f) + gn_align(sizeof(float) * hub_f));
+}
+
 // Hub sums of one or two tables [B*n][H] (T1 may be null).  On return *A0 / *A1 point at [B][n_hub][H]
-// buffers inside the handle's scratch, valid until the next call on this handle.
-int gn_hub_gather(gnode_graph_s* g, long B, int H, const float* T0, const float* T1, const float** A0, const float** A1,
-                  hipStream_t st) {
+// buffers inside `scratch` (>= gn_hub_scratch_bytes(g, B, H, T1 ? 2 : 1) bytes of the caller's workspace).
+int gn_hub_gather(const gnode_graph_s* g, long B, int H, const float* T0, const float* T1, void* scratch, const float** A0,
+                  const float** A1, hipStream_t st) {
     *A0 = nullptr;
     if (A1) *A1 = nullptr;
     if (g->n_hub == 0) return 0;
+    GN_CHECK_ARG(scratch, "hub rows present but no hub scratch was carved from the workspace");
     const int nt = T1 ? 2 : 1;
-    const size_t part_f = (size_t)B * g->n_seg * H, hub_f = (size_t)B * g->n_hub * H;
-    const size_t need = gn_align(sizeof(float) * part_f) * 2 + gn_align(sizeof(float) * hub_f) * 2;
-    if (g->hub_scratch_bytes < need) {          // grow-only cache: no allocation once warmed up for this batch size
-        GN_HIP(hipStreamSynchronize(st));
-        if (g->hub_scratch) GN_HIP(hipFree(g->hub_scratch));
-        g->hub_scratch = nullptr; g->hub_scratch_bytes = 0;
-        GN_HIP(hipMalloc(&g->hub_scratch, need));
-        g->hub_scratch_bytes = need;
-    }
-    char* base = (char*)g->hub_scratch;
+    const size_t part_b = gn_align(sizeof(float) * (size_t)B * g->n_seg * H), hub_b = gn_align(sizeof(float) * (size_t)B * g->n_hub * H);
+    char* base = (char*)scratch;
     float* P0 = (float*)base;
-    float* P1 = (float*)(base + gn_align(sizeof(float) * part_f));
-    float* a0 = (float*)(base + 2 * gn_align(sizeof(float) * part_f));
-    float* a1 = (float*)(base + 2 * gn_align(sizeof(float) * part_f) + gn_align(sizeof(float) * hub_f));
+    float* a0 = (float*)(base + part_b);
+    float* P1 = (float*)(base + part_b + hub_b);
+    float* a1 = (float*)(base + 2 * part_b + hub_b);
     const int lpr = hub_lpr(H), gpw = 256 / lpr;
     HUB_DISPATCH(lpr, hipLaunchKernelGGL(k_hub_seg<LPR>, dim3((unsigned)((g->n_seg + gpw - 1) / gpw), (unsigned)B), dim3(256), 0, st,
                                          g->seg_lo, g->seg_hi, g->col, g->n, g->n_seg, H, T0, T1, P0, P1));

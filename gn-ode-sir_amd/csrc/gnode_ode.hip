@@ -16,7 +16,6 @@
 #include "gnode_gather.h"
 #include "gnode_h64.h"
 #include <algorithm>
-#include <cstdlib>
 
 // --------------------------------------------------------------------------- error state
 static thread_local char g_err[512] = "";
@@ -27,11 +26,13 @@ void gnode_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gnode_last_error(void) { return g_err; }
-extern "C" int gnode_version(void) { return 101; }   // 101: + gnode_dmp_f32, gnode_meanfield_f64
+extern "C" int gnode_version(void) { return 200; }   // 200: workspace sizes take the graph handle (hub scratch is carved from the caller's workspace)
 
 // --------------------------------------------------------------------------- instrumentation
 // HIP-event pairs around every launch of the two step kernels while enabled
 // (bench.py's roofline leg: average launch duration measured on the launch stream).
+// PROCESS-WIDE state, documented as such in gnode.h: a measuring harness switches it on around a single-threaded
+// region; it is off by default and the launch paths then touch none of it.
 #include <vector>
 struct ProfKind { std::vector<hipEvent_t> ev; size_t used = 0; };
 static bool g_prof_on = false;
@@ -403,47 +404,47 @@ static int check_H(int H) {
         default: { constexpr int LPR = 64; __VA_ARGS__; } break; \
     }
 
-static int launch_mlp(const float* X, const float* W, const float* b, float* Z, long nrows, int H, hipStream_t st) {
+static int launch_mlp(const gnode_graph_s* g, const float* X, const float* W, const float* b, float* Z, long nrows, int H, hipStream_t st) {
     if (nrows == 0) return 0;
     const bool sampled = prof_begin(1, st);
     if (H == 64) {
-        if (int e = gn_launch_mlp64(X, W, b, Z, nrows, st)) return e;
+        if (int e = gn_launch_mlp64(g, X, W, b, Z, nrows, st)) return e;
     } else if (H == 128) {
-        if (int e = gn_launch_mlp128(X, W, b, Z, nrows, st)) return e;       // matrix cores (gnode_h128.hip)
+        if (int e = gn_launch_mlp128(g, X, W, b, Z, nrows, st)) return e;    // matrix cores (gnode_h128.hip)
     } else {
         GN_CHECK_ARG(H <= 128, "generic node-MLP path supports H <= 128 (got %d)", H);
         const int lpr = lpr_for(H);
         const int rpw = 256 / lpr;
         const size_t lds = ((size_t)H * H + (size_t)rpw * H) * sizeof(float);
-        DISPATCH_LPR(lpr, {
-            static bool attr_set = false;          // once per instantiation, never inside a stream capture
-            if (lds > 64 * 1024 && !attr_set) {
-                GN_HIP(hipFuncSetAttribute((const void*)k_mlp_generic<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(k_mlp_generic<LPR>, dim3((unsigned)((nrows + rpw - 1) / rpw)), dim3(256), lds, st, X, W, b, Z, nrows, H);
-        });
+        DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_mlp_generic<LPR>, dim3((unsigned)((nrows + rpw - 1) / rpw)), dim3(256), lds, st, X, W, b, Z, nrows, H));
     }
     if (sampled) prof_mark(1, st);
     GN_LAUNCH_CHECK();
     return 0;
 }
 
-int gn_launch_mlp_any(const float* X, const float* W, const float* b, float* Z, long nrows, int H, hipStream_t st) {
-    return launch_mlp(X, W, b, Z, nrows, H, st);
+int gn_launch_mlp_any(const gnode_graph_s* g, const float* X, const float* W, const float* b, float* Z, long nrows, int H,
+                      hipStream_t st) {
+    return launch_mlp(g, X, W, b, Z, nrows, H, st);
+}
+
+// dynamic LDS above 64 KB (H = 128 on the generic node-MLP: 68 KB) needs the attribute once per device
+int gn_ode_set_attributes() {
+    GN_HIP(hipFuncSetAttribute((const void*)k_mlp_generic<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    return 0;
 }
 
 // dY or in-place Euler update from (Y, Z)
 static int launch_gather(gnode_graph_t g, int mode, long rows, int H, float* Y, const float* Z, const float* beta,
                          const float* gamma, int bg_stride, float dt, float* dY, const gnode_params* p, StepOut out,
-                         hipStream_t st) {
+                         void* hub_scratch, hipStream_t st) {
     const int lpr = lpr_for(H), rpw = 256 / lpr;
     const long B = rows / g->n;
     dim3 grid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)B);
     const float *w3 = p ? p->linear3_weight : nullptr, *b3 = p ? p->linear3_bias : nullptr;
     const float *w2 = p ? p->linearS2_weight : nullptr, *b2 = p ? p->linearS2_bias : nullptr;
     const float* AIhub = nullptr;
-    if (int e = gn_hub_gather(g, B, H, Z + (size_t)rows * H, nullptr, &AIhub, nullptr, st)) return e;
+    if (int e = gn_hub_gather(g, B, H, Z + (size_t)rows * H, nullptr, hub_scratch, &AIhub, nullptr, st)) return e;
     const bool sampled = mode == 1 && prof_begin(0, st);
     if (mode == 0) {
         DISPATCH_LPR(lpr, hipLaunchKernelGGL((k_gather<LPR, 0>), grid, dim3(256), 0, st, g->rowptr, g->col, g->n, rows, H,
@@ -468,6 +469,30 @@ static int launch_readout(const float* Y, long rows, int H, const gnode_params* 
 }
 
 // --------------------------------------------------------------------------- graph handle
+// Per-device one-time setup, done when the first graph handle is created on a device (never on a launch path, so
+// never inside a stream capture): dynamic-LDS attributes of every kernel that can ask for more than 64 KB, and the
+// device's CU count.  The only process-wide state besides the opt-in profiler: write-once per device, under a lock.
+#include <mutex>
+static std::mutex g_dev_mu;
+static bool g_dev_done[64] = {};
+static int g_dev_cu[64] = {};
+int gn_device_setup_once(int dev) {
+    GN_CHECK_ARG(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (g_dev_done[dev]) return 0;
+    hipDeviceProp_t prop;
+    GN_HIP(hipGetDeviceProperties(&prop, dev));
+    g_dev_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (int e = gn_ode_set_attributes()) return e;
+    if (int e = gn_h64_set_attributes()) return e;
+    if (int e = gn_h128_set_attributes()) return e;
+    if (int e = gn_bwd_set_attributes()) return e;
+    if (int e = gn_bwd_tiny_set_attributes()) return e;
+    if (int e = gn_sir_set_attributes()) return e;
+    g_dev_done[dev] = true;
+    return 0;
+}
+
 extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col_host, int32_t n, int64_t nnz,
                                   gnode_graph_t* out) {
     GN_CHECK_ARG(rowptr_host && out && n > 0 && nnz >= 0, "gnode_graph_create: null pointer or empty graph");
@@ -482,10 +507,14 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
     for (int64_t e = 0; e < nnz; ++e)
         GN_CHECK_ARG(col_host[e] >= 0 && col_host[e] < n, "gnode_graph_create: col[%lld]=%d out of range",
                      (long long)e, col_host[e]);
+    int dev = 0;
+    GN_HIP(hipGetDevice(&dev));
+    if (int e = gn_device_setup_once(dev)) return e;
     gnode_graph_s* g = new gnode_graph_s();
     g->n = n; g->nnz = nnz; g->max_degree = maxdeg; g->rowptr = nullptr; g->col = nullptr;
     g->n_hub = g->n_seg = 0; g->hubidx = g->seg_lo = g->seg_hi = g->hub_seg_ptr = nullptr;
-    g->hub_scratch = nullptr; g->hub_scratch_bytes = 0;
+    g->device = dev;
+    g->num_cu = g_dev_cu[dev];
     hipError_t e1 = hipMalloc(&g->rowptr, sizeof(int32_t) * (size_t)(n + 1));
     hipError_t e2 = hipMalloc(&g->col, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -533,8 +562,9 @@ extern "C" int gnode_graph_info(gnode_graph_t g, int32_t* n, int64_t* nnz, int32
 }
 
 // --------------------------------------------------------------------------- RHS
-extern "C" size_t gnode_rhs_workspace_bytes(int64_t rows, int32_t H) {
-    return gn_align((size_t)2 * rows * H * sizeof(float));
+extern "C" size_t gnode_rhs_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H) {
+    if (!g || rows <= 0 || H <= 0) return 0;
+    return gn_align((size_t)2 * rows * H * sizeof(float)) + gn_hub_scratch_bytes(g, rows / g->n, H, 1);
 }
 
 extern "C" int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* b, float* dx, int64_t rows,
@@ -544,28 +574,36 @@ extern "C" int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, co
     GN_CHECK_ARG(H >= 2, "gnode_rhs_f32: H >= 2 required (beta, gamma live in columns 0, 1)");
     GN_CHECK_ARG(rows > 0 && rows % g->n == 0, "gnode_rhs_f32: rows=%lld is not a multiple of graph n=%d",
                  (long long)rows, g->n);
-    if (workspace_bytes < gnode_rhs_workspace_bytes(rows, H)) {
-        gnode_set_error("gnode_rhs_f32: workspace %zu < %zu", workspace_bytes, gnode_rhs_workspace_bytes(rows, H));
+    if (workspace_bytes < gnode_rhs_workspace_bytes(g, rows, H)) {
+        gnode_set_error("gnode_rhs_f32: workspace %zu < %zu", workspace_bytes, gnode_rhs_workspace_bytes(g, rows, H));
         return GNODE_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
     float* Z = (float*)workspace;
+    void* hub_scratch = (char*)workspace + gn_align((size_t)2 * rows * H * sizeof(float));
     const size_t slab = (size_t)rows * H;
-    if (int e = launch_mlp(x, W, b, Z, 2 * rows, H, st)) return e;      // R' is dead work in the reference: skipped
+    if (int e = launch_mlp(g, x, W, b, Z, 2 * rows, H, st)) return e;   // R' is dead work in the reference: skipped
     StepOut none = {nullptr, nullptr, nullptr, nullptr};
     if (int e = launch_gather(g, 0, rows, H, const_cast<float*>(x), Z, x + 3 * slab, x + 3 * slab + 1, H, 0.f, dx,
-                              nullptr, none, st))
+                              nullptr, none, hub_scratch, st))
         return e;
     GN_HIP(hipMemsetAsync(dx + 3 * slab, 0, slab * sizeof(float), st));  // 4th slab derivative = 0 (:96)
     return 0;
 }
 
 // --------------------------------------------------------------------------- forward
-extern "C" size_t gnode_forward_workspace_bytes(int64_t rows, int32_t H, int32_t method) {
+static size_t forward_fixed_bytes(int64_t rows, int32_t H, int32_t method) {
     const size_t slab = gn_align((size_t)rows * H * sizeof(float));
     size_t nslab = 5;                       // Y[3], Z[2]
     if (method == 1) nslab += 3 * 5;        // k1..k4, ytmp (3 slabs each)
-    return nslab * slab + 2 * gn_align((size_t)rows * sizeof(float)) + gn_align((size_t)rows * 4 * sizeof(float));
+    // + one 256-B ZERO ROW behind each of the two gather tables (H = 64 step kernel: rows shorter than the gather
+    //   width read it instead of branching per neighbour)
+    return nslab * slab + 512 + 2 * gn_align((size_t)rows * sizeof(float)) + gn_align((size_t)rows * 4 * sizeof(float));
+}
+
+extern "C" size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t method) {
+    if (!g || rows <= 0 || H <= 0) return 0;
+    return forward_fixed_bytes(rows, H, method) + gn_hub_scratch_bytes(g, rows / g->n, H, 1);
 }
 
 extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
@@ -582,9 +620,9 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
     GN_CHECK_ARG(p->odefunc_linear_weight && p->odefunc_linear_bias && p->linearS1_weight && p->linearS1_bias &&
                      p->linear3_weight && p->linear3_bias && p->linearS2_weight && p->linearS2_bias,
                  "gnode_forward_f32: null parameter pointer");
-    if (workspace_bytes < gnode_forward_workspace_bytes(rows, H, method)) {
+    if (workspace_bytes < gnode_forward_workspace_bytes(g, rows, H, method)) {
         gnode_set_error("gnode_forward_f32: workspace %zu < %zu", workspace_bytes,
-                        gnode_forward_workspace_bytes(rows, H, method));
+                        gnode_forward_workspace_bytes(g, rows, H, method));
         return GNODE_ERR_WORKSPACE;
     }
     const int G = n_steps + 1;
@@ -600,10 +638,12 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
     float* Y = (float*)ws;                       // [3][rows][H] (contiguous: slab strides are elements, not aligned bytes)
     // keep slabs element-contiguous: Y uses 3*slab floats inside 3 aligned slabs
     float* Z = (float*)(ws + 3 * slab_b);
-    float* beta = (float*)(ws + 5 * slab_b);
-    float* gamma = (float*)(ws + 5 * slab_b + gn_align((size_t)rows * sizeof(float)));
-    float* prbuf = (float*)(ws + 5 * slab_b + 2 * gn_align((size_t)rows * sizeof(float)));
-    float* rk = (float*)(ws + 5 * slab_b + 2 * gn_align((size_t)rows * sizeof(float)) + gn_align((size_t)rows * 4 * sizeof(float)));
+    char* after_z = ws + 5 * slab_b + 512;     // Z: [table 0][zero row][table 1][zero row] on the H = 64 path
+    float* beta = (float*)after_z;
+    float* gamma = (float*)(after_z + gn_align((size_t)rows * sizeof(float)));
+    float* prbuf = (float*)(after_z + 2 * gn_align((size_t)rows * sizeof(float)));
+    float* rk = (float*)(after_z + 2 * gn_align((size_t)rows * sizeof(float)) + gn_align((size_t)rows * 4 * sizeof(float)));
+    void* hub_scratch = ws + forward_fixed_bytes(rows, H, method);      // segment partials + hub sums (graphs with hub rows)
 
     const int lpr = lpr_for(H), rpw = 256 / lpr;
     int next_out = 0;  // index into the output list
@@ -614,17 +654,15 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
     };
     int slot = out_slot(0);
 
-    // H = 64: fused step kernels (gnode_h64.hip).  GNODE_FUSE=0 keeps Z_I in its own node-MLP launch.
+    // H = 64: fused step kernels (gnode_h64.hip)
     const bool h64 = (H == 64 && method == 0);
-    static const bool fuse_zi = [] { const char* e = getenv("GNODE_FUSE"); return !(e && e[0] == '0'); }();
     float* zi_cur = Z;
-    float* zi_nxt = Z + slab;
+    float* zi_nxt = Z + slab + (h64 ? 64 : 0);           // H = 64: each table is followed by its zero row
     // inference (no trajectory requested): R only feeds the read-out -> carry its 4-float projection
-    static const bool prj_ok = [] { const char* e = getenv("GNODE_PRJ"); return !(e && e[0] == '0'); }();
-    float* PR = (h64 && !sol && prj_ok) ? prbuf : nullptr;
+    float* PR = (h64 && !sol) ? prbuf : nullptr;
     if (h64 && n_steps > 0) {
         // encoder, beta/gamma, trajectory point 0, read-out at grid point 0, projected R and Z_I(y_0): one launch
-        if (int e = gn_launch_prologue64(x, p, Y, beta, gamma, sol, zi_cur, PR, slot >= 0 ? S + (size_t)slot * rows : nullptr,
+        if (int e = gn_launch_prologue64(x, p, Y, beta, gamma, sol, zi_cur, zi_nxt, PR, slot >= 0 ? S + (size_t)slot * rows : nullptr,
                                          slot >= 0 ? I + (size_t)slot * rows : nullptr,
                                          slot >= 0 ? R + (size_t)slot * rows : nullptr, rows, st))
             return e;
@@ -636,9 +674,9 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
             if (int e = launch_readout(Y, rows, H, p, S + (size_t)slot * rows, I + (size_t)slot * rows, R + (size_t)slot * rows, st))
                 return e;
         if (method == 0 && H < 128 && n_steps > 0)
-            if (int e = launch_mlp(Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
+            if (int e = launch_mlp(g, Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
     }
-    if (h64 && fuse_zi && gn_tiny64_ok(g->n, n_steps, out_rows_host ? n_out : G, PR != nullptr)) {
+    if (h64 && gn_tiny64_ok(g->n, n_steps, out_rows_host ? n_out : G, PR != nullptr)) {
         // tiny graphs: the whole integration in one launch (one workgroup per sample, state in LDS)
         int slots[128];
         for (int k = 0; k < n_steps; ++k) slots[k] = out_slot(k + 1);
@@ -664,42 +702,33 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
                              slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
             const bool sampled = prof_begin(0, st);
             if (int e = gn_launch_step64(g, rows, Ycur, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,
-                                         gamma, dt, p, PR, out, fuse_zi, st))
+                                         gamma, dt, p, PR, out, hub_scratch, st))
                 return e;
             if (sampled) prof_mark(0, st);
-            if (fuse_zi) std::swap(zi_cur, zi_nxt);
-            else if (k + 1 < n_steps)
-                if (int e = launch_mlp((sol_next ? sol_next : Y) + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur,
-                                       rows, H, st))
-                    return e;
+            std::swap(zi_cur, zi_nxt);
         } else if (method == 0 && H < 128) {
             // generic H: one fused launch per step (gather + both node MLPs as lane-group mat-vecs); H = 128 takes the
             // two-launch branch below, whose node MLP runs on the matrix cores (a VALU mat-vec is 12x off the bound there)
             StepOut out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
                            slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
             const float* AIhub = nullptr;
-            if (int e = gn_hub_gather(g, rows / g->n, H, zi_cur, nullptr, &AIhub, nullptr, st)) return e;
+            if (int e = gn_hub_gather(g, rows / g->n, H, zi_cur, nullptr, hub_scratch, &AIhub, nullptr, st)) return e;
             dim3 grid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)(rows / g->n));
             const size_t lds = (size_t)H * H * sizeof(float);
             const bool sampled = prof_begin(0, st);
-            DISPATCH_LPR(lpr, {
-                static bool attr_set = false;
-                if (lds > 64 * 1024 && !attr_set) {
-                    GN_HIP(hipFuncSetAttribute((const void*)k_step_generic<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    attr_set = true;
-                }
-                hipLaunchKernelGGL(k_step_generic<LPR>, grid, dim3(256), lds, st, g->rowptr, g->col, g->n, (long)rows, H, Ycur, zi_cur,
-                                   zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma, dt, p->linear3_weight,
-                                   p->linear3_bias, p->linearS2_weight, p->linearS2_bias, out, g->hubidx, AIhub, g->n_hub);
-            });
+            // (H < 128 here: W^T is at most 61 KB of dynamic LDS, below the 64 KB that would need an attribute)
+            DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_step_generic<LPR>, grid, dim3(256), lds, st, g->rowptr, g->col, g->n, (long)rows, H,
+                                                 Ycur, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma,
+                                                 dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, out,
+                                                 g->hubidx, AIhub, g->n_hub));
             if (sampled) prof_mark(0, st);
             GN_LAUNCH_CHECK();
             std::swap(zi_cur, zi_nxt);
         } else if (method == 0) {
-            if (int e = launch_mlp(Y, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
+            if (int e = launch_mlp(g, Y, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
             StepOut out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
                            slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
-            if (int e = launch_gather(g, 1, rows, H, Y, Z, beta, gamma, 1, dt, nullptr, p, out, st)) return e;
+            if (int e = launch_gather(g, 1, rows, H, Y, Z, beta, gamma, 1, dt, nullptr, p, out, hub_scratch, st)) return e;
         } else {
             // torchdiffeq 'rk4' = 3/8 rule
             float* k1 = rk; float* k2 = rk + 3 * slab; float* k3 = rk + 6 * slab; float* k4 = rk + 9 * slab;
@@ -708,8 +737,8 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
             const int eg = (int)std::min<size_t>((n4 + 255) / 256, 2048);
             StepOut none = {nullptr, nullptr, nullptr, nullptr};
             auto f = [&](float* y, float* kout) -> int {
-                if (int e = launch_mlp(y, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
-                return launch_gather(g, 0, rows, H, y, Z, beta, gamma, 1, 0.f, kout, nullptr, none, st);
+                if (int e = launch_mlp(g, y, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
+                return launch_gather(g, 0, rows, H, y, Z, beta, gamma, 1, 0.f, kout, nullptr, none, hub_scratch, st);
             };
             const float third = 1.0f / 3.0f;
             if (int e = f(Y, k1)) return e;

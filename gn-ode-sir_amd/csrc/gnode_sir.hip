@@ -222,6 +222,17 @@ __global__ __launch_bounds__(256) void k_sir_coins(const int* __restrict__ tsrc,
 // --------------------------------------------------------------------------- host side
 static const size_t kLdsStateLimit = 150 * 1024;   // of the CU's 160 KiB
 
+struct SeedArg { int32_t v[32]; };
+__global__ void k_put_seeds(SeedArg sa, int n_seeds, int32_t* __restrict__ seeds) {
+    if ((int)threadIdx.x < n_seeds) seeds[threadIdx.x] = sa.v[threadIdx.x];
+}
+
+int gn_sir_set_attributes() {       // once per device, from gnode_graph_create
+    GN_HIP(hipFuncSetAttribute((const void*)k_sir_philox<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
+    GN_HIP(hipFuncSetAttribute((const void*)k_sir_coins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
+    return 0;
+}
+
 extern "C" size_t gnode_sir_coins_workspace_bytes(void) { return gn_align(4096 * sizeof(int32_t)) + gn_align(64); }
 
 extern "C" size_t gnode_sir_workspace_bytes(gnode_graph_t g, int32_t T) {
@@ -255,8 +266,18 @@ extern "C" int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, i
     uint8_t* gstate = (uint8_t*)(ws + hist_b + gn_align(4096 * sizeof(int32_t)) +
                                  gn_align((size_t)std::max<int64_t>(g->nnz, 1) * sizeof(int32_t)));
     GN_HIP(hipMemsetAsync(hist, 0, hist_b, st));
-    if (n_seeds) GN_HIP(hipMemcpyAsync(seeds, seeds_host, sizeof(int32_t) * n_seeds, hipMemcpyHostToDevice, st));
-    GN_HIP(hipStreamSynchronize(st));    // seeds_host may be a temporary of the caller
+    // seed ids: up to 32 travel as a kernel argument (no copy, no synchronisation -- the reference's experiments use 2);
+    // longer lists are copied from the caller's host array, which may be a temporary, so the stream is synchronised
+    // before returning control (documented in gnode.h)
+    SeedArg sa;
+    for (int i = 0; i < 32; ++i) sa.v[i] = i < n_seeds ? seeds_host[i] : 0;
+    if (n_seeds <= 32) {
+        hipLaunchKernelGGL(k_put_seeds, dim3(1), dim3(32), 0, st, sa, n_seeds, seeds);
+        GN_LAUNCH_CHECK();
+    } else {
+        GN_HIP(hipMemcpyAsync(seeds, seeds_host, sizeof(int32_t) * n_seeds, hipMemcpyHostToDevice, st));
+        GN_HIP(hipStreamSynchronize(st));
+    }
     hipLaunchKernelGGL(k_expand_rows, dim3((g->n + 255) / 256), dim3(256), 0, st, g->rowptr, g->n, src);
     GN_LAUNCH_CHECK();
     const unsigned long long tb = (unsigned long long)std::min(4294967296.0, std::max(0.0, std::floor(beta * 4294967296.0)));
@@ -265,12 +286,10 @@ extern "C" int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, i
     if (sims > 0) {
         const size_t lds = (size_t)2 * g->n;
         if (lds <= kLdsStateLimit) {
-            if (lds > 64 * 1024)
-                GN_HIP(hipFuncSetAttribute((const void*)k_sir_philox<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             // workgroups per CU by LDS; keep >= 16 waves per CU: big states get 1024-thread workgroups
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
             const int threads = per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024);
-            const int grid = (int)std::min<int64_t>(sims, 256 * per_cu);
+            const int grid = (int)std::min<int64_t>(sims, (int64_t)g->num_cu * per_cu);
             hipLaunchKernelGGL(k_sir_philox<true>, dim3(grid), dim3(threads), lds, st, src, g->col, (long)g->nnz, g->n, seeds,
                                n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (uint8_t*)nullptr);
         } else {
@@ -304,8 +323,11 @@ extern "C" int gnode_sir_mc_coins(const int32_t* table_src, const int32_t* table
     int32_t* seeds = (int32_t*)workspace;
     long long* used = (long long*)((char*)workspace + gn_align(4096 * sizeof(int32_t)));
     if (n_seeds) GN_HIP(hipMemcpyAsync(seeds, seeds_host, sizeof(int32_t) * n_seeds, hipMemcpyHostToDevice, st));
-    if ((size_t)2 * n > 64 * 1024)
-        GN_HIP(hipFuncSetAttribute((const void*)k_sir_coins, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * n));
+    {   // the parity kernel takes no graph handle: make sure this device's kernel attributes are set (once, under the lock)
+        int dev = 0;
+        GN_HIP(hipGetDevice(&dev));
+        if (int e = gn_device_setup_once(dev)) return e;
+    }
     hipLaunchKernelGGL(k_sir_coins, dim3(1), dim3(256), (size_t)2 * n, st, table_src, table_dst, (long)n_table, n, seeds,
                        n_seeds, beta, gamma, (long)sims, T, coins, (long)n_coins, counts, used);
     GN_LAUNCH_CHECK();

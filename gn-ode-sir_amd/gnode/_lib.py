@@ -61,10 +61,10 @@ def load():
     lib.gnode_graph_create.argtypes = [vp, vp, i32, i64, C.POINTER(vp)]
     lib.gnode_graph_destroy.argtypes = [vp]
     lib.gnode_graph_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]
-    lib.gnode_rhs_workspace_bytes.argtypes = [i64, i32]
+    lib.gnode_rhs_workspace_bytes.argtypes = [vp, i64, i32]
     lib.gnode_rhs_workspace_bytes.restype = sz
     lib.gnode_rhs_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, sz, vp]
-    lib.gnode_forward_workspace_bytes.argtypes = [i64, i32, i32]
+    lib.gnode_forward_workspace_bytes.argtypes = [vp, i64, i32, i32]
     lib.gnode_forward_workspace_bytes.restype = sz
     lib.gnode_forward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp, sz, vp]
     lib.gnode_meanfield_workspace_bytes.argtypes = [vp]
@@ -74,7 +74,7 @@ def load():
     lib.gnode_dmp_workspace_bytes.argtypes = [vp]
     lib.gnode_dmp_workspace_bytes.restype = sz
     lib.gnode_dmp_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
-    lib.gnode_backward_workspace_bytes.argtypes = [i64, i32]
+    lib.gnode_backward_workspace_bytes.argtypes = [vp, i64, i32]
     lib.gnode_backward_workspace_bytes.restype = sz
     lib.gnode_backward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, vp, i32, vp, vp, vp, vp,
                                        C.POINTER(Params), i64, i32, vp, sz, vp]
@@ -90,6 +90,8 @@ def load():
     for fn in ("gnode_graph_create", "gnode_graph_destroy", "gnode_graph_info", "gnode_rhs_f32", "gnode_forward_f32",
                "gnode_sir_mc_philox", "gnode_sir_mc_coins"):
         getattr(lib, fn).restype = C.c_int
+    if lib.gnode_version() < 200:
+        raise GnodeError(f"{LIB_PATH} is stale (ABI {lib.gnode_version()} < 200): rebuild it (gnode.build.build_lib)")
     _lib = lib
     return lib
 

@@ -61,7 +61,7 @@ def rhs(graph: DeviceGraph, x: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -
         raise _lib.GnodeError("state must have 4 slabs")
     rows = rows4 // 4
     dx = torch.empty_like(x)
-    ws = _workspace(lib.gnode_rhs_workspace_bytes(rows, H), x.device)
+    ws = _workspace(lib.gnode_rhs_workspace_bytes(graph.handle, rows, H), x.device)
     _lib.check(lib.gnode_rhs_f32(graph.handle, _lib.ptr(x), _lib.ptr(_f32c(W)), _lib.ptr(_f32c(b)), _lib.ptr(dx), rows, H,
                                  _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
     return dx
@@ -85,7 +85,7 @@ def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray
     dev = x2d.device
     out = torch.empty((3, n_out, rows), dtype=torch.float32, device=dev)
     sol = torch.empty((n_steps + 1, 4 * rows, H), dtype=torch.float32, device=dev) if want_sol else None
-    need = lib.gnode_forward_workspace_bytes(rows, H, m)
+    need = lib.gnode_forward_workspace_bytes(graph.handle, rows, H, m)
     ws = workspace if (workspace is not None and workspace.numel() >= need) else _workspace(need, dev)
     p = pack_params(params)
     _lib.check(lib.gnode_forward_f32(
@@ -116,7 +116,7 @@ def backward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarra
         if tuple(t.shape) != (n_out, rows):
             raise _lib.GnodeError(f"upstream gradient shape {tuple(t.shape)} != {(n_out, rows)}")
     grads = {k: torch.empty_like(params[k], memory_format=torch.contiguous_format) for k in PARAM_KEYS}
-    ws = _workspace(lib.gnode_backward_workspace_bytes(rows, H), x2d.device)
+    ws = _workspace(lib.gnode_backward_workspace_bytes(graph.handle, rows, H), x2d.device)
     p, gp = pack_params({k: v.detach() for k, v in params.items()}), pack_params(grads)
     _lib.check(lib.gnode_backward_f32(
         graph.handle, _lib.ptr(x2d), C.byref(p), _lib.host_ptr(dts), n_steps,

@@ -13,9 +13,21 @@
  *     over torch tensors' data_ptr()); the library never frees or retains them
  *     past the call.  "host" pointers are ordinary memory, read before return.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
- *     All work is enqueued on it; nothing synchronises the device except where
- *     a function says so.  The launch functions do no allocation, so they can be
- *     captured into a hipGraph by the caller.
+ *     All work is enqueued on it.  gnode_rhs_f32, gnode_forward_f32 and
+ *     gnode_backward_f32 allocate nothing, synchronise nothing and keep nothing in
+ *     the graph handle: every byte of scratch (including the partial sums of long
+ *     "hub" rows) is carved from the caller's workspace, so they can be captured
+ *     into a hipGraph on first use and one handle may serve several streams (each
+ *     with its own workspace).  Functions that DO synchronise `stream` say so below
+ *     (gnode_graph_create, gnode_sir_mc_philox with more than 32 seeds,
+ *     gnode_sir_mc_coins, gnode_dmp_f32, gnode_meanfield_f64).
+ *   - process-wide state: (1) a per-device "set up once" table (compute-unit count,
+ *     dynamic-LDS kernel attributes), written under a lock by the first
+ *     gnode_graph_create on a device and read-only afterwards; (2) the opt-in
+ *     launch profiler of gnode_profile_enable (off by default; while it is on, use
+ *     the library from one thread); (3) the thread-local error string.  Nothing
+ *     else: no environment variable is read, no kernel variant is selected at
+ *     run time other than by the arguments.
  *   - all floating point is IEEE fp32 (the reference builds its model under
  *     torch.float32, ode_nn_ngraph_sim.py:433); indices are int32.
  *   - row layout is the reference's own: a batch of B samples on one graph of n
@@ -73,8 +85,9 @@ int gnode_graph_info(gnode_graph_t g, int32_t* n, int64_t* nnz, int32_t* max_deg
 /* ---- RHS -----------------------------------------------------------------
  * ODEfunc.forward(t, x): ode_nn_ngraph_sim.py:58-96 (multi: ode_nn_ngraphs.py:54-83).
  * x, dx: device [4*rows, H], slabs S | I | R | beta-gamma (col 0 beta, col 1 gamma).
- * workspace: device, >= gnode_rhs_workspace_bytes(rows, H). */
-size_t gnode_rhs_workspace_bytes(int64_t rows, int32_t H);
+ * workspace: device, >= gnode_rhs_workspace_bytes(g, rows, H) (the size depends on the
+ * graph: long rows are summed through scratch carved from the workspace). */
+size_t gnode_rhs_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H);
 int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* b, float* dx,
                   int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -90,8 +103,8 @@ int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* 
  *   S, I, R    device [n_out, rows] each (the reference's [G, rows, 1])
  *   sol        NULL, or device [n_steps+1, 4*rows, H]: the trajectory odeint
  *              returns (needed by the adjoint backward, never by inference)
- *   workspace  device, >= gnode_forward_workspace_bytes(rows, H, method) */
-size_t gnode_forward_workspace_bytes(int64_t rows, int32_t H, int32_t method);
+ *   workspace  device, >= gnode_forward_workspace_bytes(g, rows, H, method) */
+size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t method);
 int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
                       int32_t n_steps, int32_t method, const int32_t* out_rows_host, int32_t n_out,
                       float* S, float* I, float* R, float* sol, int64_t rows, int32_t H,
@@ -105,8 +118,9 @@ int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, co
  *   gS, gI, gR   device [n_out, rows] upstream gradients of the outputs
  *   grads        device pointers (same struct as the parameters) that RECEIVE
  *                dL/dparam (overwritten, not accumulated)
- * Euler only (the reference's method).  Deterministic (no float atomics). */
-size_t gnode_backward_workspace_bytes(int64_t rows, int32_t H);
+ * Euler only (the reference's method).  Deterministic (no float atomics).
+ *   workspace  device, >= gnode_backward_workspace_bytes(g, rows, H) */
+size_t gnode_backward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H);
 int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
                        int32_t n_steps, const int32_t* out_rows_host, int32_t n_out, const float* sol,
                        const float* gS, const float* gI, const float* gR, const gnode_params* grads,
@@ -121,6 +135,8 @@ int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_params* p, c
  * counts.  counts: device uint32 [3, T, n] (S, I, R), ACCUMULATED into (caller
  * zeroes it); rows t >= 1 add one per trajectory per node, row 0 of S and I is
  * written with the initial state once (reference quirk: assigned, ode_nn.py:55-56).
+ * Up to 32 seeds travel as a kernel argument (nothing is synchronised); with more,
+ * seeds_host is copied and `stream` is synchronised before the function returns.
  *
  * gnode_sir_mc_coins: parity mode.  Consumes a recorded coin stream exactly as
  * the reference consumes torch.rand (ode_nn.py:65,70): per step first one coin
@@ -149,6 +165,7 @@ int gnode_sir_mc_coins(const int32_t* table_src, const int32_t* table_dst, int64
  *   gamma     device fp32 [n]     recovery probability of each node (dmp.py:349)
  *   out       device fp32 [maxTime, n, 3] = (Ps, Pi, Pr), row 0 = initial state
  *                                 (`DMP_SIR.output()`, dmp.py:159-162)
+ * Synchronises `stream` (host arrays are staged through the workspace).
  * Not on the `model='ode_nn'` path: a comparison column of the paper. */
 size_t gnode_dmp_workspace_bytes(gnode_graph_t g);
 int gnode_dmp_f32(gnode_graph_t g, const float* weights, const float* gamma, const int32_t* seeds_host,
@@ -175,7 +192,8 @@ int gnode_meanfield_f64(gnode_graph_t g, const int32_t* seeds_host, int32_t n_se
  * While enabled, every launch of the two step kernels (0: gather + SIR update +
  * read-out, 1: node MLP) is bracketed by HIP events on the launch stream;
  * gnode_profile_read waits for them and returns summed milliseconds and launch
- * counts.  Used by bench.py's roofline leg; off by default (no overhead). */
+ * counts.  Used by bench.py's roofline leg; off by default (no overhead).
+ * Process-wide and not thread-safe: switch it on around a single-threaded region. */
 int gnode_profile_enable(int on);
 int gnode_profile_read(double* gather_ms, int64_t* gather_launches, double* mlp_ms, int64_t* mlp_launches);
 

@@ -35,10 +35,12 @@ def test_binding_table_matches_header(lib):
 
 
 def test_version_and_sizes(lib):
-    assert lib.gnode_version() >= 100
-    assert lib.gnode_rhs_workspace_bytes(1000, 64) >= 2 * 1000 * 64 * 4
-    assert lib.gnode_forward_workspace_bytes(1000, 64, 0) >= 5 * 1000 * 64 * 4
-    assert lib.gnode_forward_workspace_bytes(1000, 64, 1) > lib.gnode_forward_workspace_bytes(1000, 64, 0)
+    assert lib.gnode_version() >= 200
+    # workspace sizes depend on the graph (hub scratch): without a handle they answer 0 instead of guessing
+    # (real sizes are exercised on the GPU: tests/test_gpu_abi.py)
+    assert lib.gnode_rhs_workspace_bytes(None, 1000, 64) == 0
+    assert lib.gnode_forward_workspace_bytes(None, 1000, 64, 0) == 0
+    assert lib.gnode_backward_workspace_bytes(None, 1000, 64) == 0
 
 
 def test_product_path_has_no_cpu_fallback():
