@@ -24,6 +24,7 @@
 // launches (fixed grid, fixed row->workgroup map); one final kernel sums the slots in
 // order.  No float atomics, bitwise reproducible run to run.
 #include "gnode_bwd.h"
+#include "gnode_h64.h"
 #include "gnode_gather.h"
 #include "gnode_mfma64.h"
 #include "gnode_head64.h"
@@ -347,6 +348,33 @@ __device__ __forceinline__ void gather2_row64(const int* __restrict__ rowptr, co
     }
 }
 
+// one table (Gq = A q) when the forward kept A Z_I(y_i): 2 NB row loads in flight per lane group, ascending column order
+template <int NB = 4>
+__device__ __forceinline__ float4 gather1_row64(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                const float* __restrict__ T0, int node, bool valid, int sub) {
+    float4 acc = zero4();
+    int start = 0, end = 0;
+    if (valid) { start = rowptr[node]; end = rowptr[node + 1]; }
+    const unsigned lane_b = 16u * sub;
+    for (int e0 = start; e0 < end; e0 += 16) {
+        const int cnt = min(16, end - e0);
+        const unsigned mine = (sub < cnt) ? (unsigned)col[e0 + sub] * 256u : 0u;
+#define GN_LD1(K, U) float4 U = zero4(); if (K < cnt) U = ld4o(T0, (unsigned)row_bcast<(K) & 15>((int)mine) + lane_b);
+#define GN_AC1(U) acc.x += U.x; acc.y += U.y; acc.z += U.z; acc.w += U.w;
+#define GN_G8(J)                                                                                   \
+        if (J < cnt) {                                                                             \
+            GN_LD1(J, u0) GN_LD1(J + 1, u1) GN_LD1(J + 2, u2) GN_LD1(J + 3, u3)                    \
+            GN_LD1(J + 4, u4) GN_LD1(J + 5, u5) GN_LD1(J + 6, u6) GN_LD1(J + 7, u7)                \
+            GN_AC1(u0) GN_AC1(u1) GN_AC1(u2) GN_AC1(u3) GN_AC1(u4) GN_AC1(u5) GN_AC1(u6) GN_AC1(u7) \
+        }
+        GN_G8(0) GN_G8(8)
+#undef GN_G8
+#undef GN_AC1
+#undef GN_LD1
+    }
+    return acc;
+}
+
 #ifndef GN_BWD_RPG1_OCC
 #define GN_BWD_RPG1_OCC 3
 #endif
@@ -355,7 +383,9 @@ __device__ __forceinline__ void gather2_row64(const int* __restrict__ rowptr, co
                              // interval on the 75k graph x 4, 4: 456 us; mid-size train steps -5 %)
 #endif
 static_assert(GN_BWD_RPG1_OCC * 256 <= BWD_NWG, "fused backward grid exceeds the partial-gradient slots");
-template <int OCC, int RPG>
+// GATHER_AI: gather A Z_I as well (the last grid point, and trajectories whose 4th slabs do not carry it); otherwise the
+// row's A Z_I(y_i) is read back from `AIsaved` (the forward kept it) and only A q is gathered: one table instead of two.
+template <int OCC, int RPG, bool GATHER_AI>
 __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                      long rows, int tiles_per_sample, long total_tiles,
                                                      float* __restrict__ ZS, const float* __restrict__ ZIc,
@@ -369,7 +399,8 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
                                                      const float* __restrict__ w3, const float* __restrict__ b3,
                                                      const float* __restrict__ w2, const float* __restrict__ b2,
                                                      const int* __restrict__ hubidx, const float* __restrict__ AIhub,
-                                                     const float* __restrict__ GQhub, int n_hub, int do_next) {
+                                                     const float* __restrict__ GQhub, int n_hub, int do_next,
+                                                     const float* __restrict__ AIsaved) {
     __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
     constexpr int TR = 16 * RPG;                   // rows per tile (RPG rows per 16-lane group)
     __shared__ __attribute__((aligned(16))) float tiles[4][TR * TS];
@@ -417,11 +448,17 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
             }
             float4 ai, gq;
             const int hub = (hubidx && valid[p]) ? hubidx[node] : -1;
-            if (hub >= 0) {
-                ai = ld4g(AIhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
-                gq = ld4g(GQhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+            if (GATHER_AI) {
+                if (hub >= 0) {
+                    ai = ld4g(AIhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+                    gq = ld4g(GQhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+                } else {
+                    gather2_row64<GN_BWD_NB>(rowptr, col, ZIc + (size_t)base * 64, Qc + (size_t)base * 64, node, valid[p], sub, ai, gq);
+                }
             } else {
-                gather2_row64<GN_BWD_NB>(rowptr, col, ZIc + (size_t)base * 64, Qc + (size_t)base * 64, node, valid[p], sub, ai, gq);
+                ai = valid[p] ? ld4g(AIsaved + off[p]) : zero4();
+                if (hub >= 0) gq = ld4g(GQhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+                else gq = gather1_row64<>(rowptr, col, Qc + (size_t)base * 64, node, valid[p], sub);
             }
             if (valid[p]) {
 #define GN_DP(c)                                                               \
@@ -902,23 +939,30 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         GN_LAUNCH_CHECK();
         // 16-row tiles at 3 workgroups per CU (measured on the 75k graph, 4 samples: 32-row tiles at 3 / 2 per CU 481 / 548 us
         // per interval, the unfused three-launch form 563; 16-row tiles 451)
-        auto fused_kernel = k_bwd_fused64<GN_BWD_RPG1_OCC, 1>;
+        // does this trajectory carry A Z_I(y_i) in its 4th slabs (gnode_forward_f32 wrote it: H = 64, not the one-launch path)?
+        const bool ai_saved = gn_sol_carries_ai(g, H, n_steps, out_rows_host ? n_out : G);
         const int tps = (g->n + 15) / 16;
         const long total = (long)(rows / g->n) * tps;
         const int grid = (int)std::min<long>(std::min<long>((long)GN_BWD_RPG1_OCC * g->num_cu, BWD_NWG), total);
         slots_used = std::max(slots_used, grid);
         for (int i = G - 1; i >= 1; --i) {
             const int cur = (G - 1 - i) & 1;
+            const bool two = !ai_saved || i == G - 1;          // A Z_I(y_{G-1}) was never needed by the forward
             const float *AIhub = nullptr, *GQhub = nullptr;
-            if (int e = gn_hub_gather(g, rows / g->n, 64, ZIb[cur], Qb[cur], hub_scratch, &AIhub, &GQhub, st)) return e;
+            if (two) { if (int e = gn_hub_gather(g, rows / g->n, 64, ZIb[cur], Qb[cur], hub_scratch, &AIhub, &GQhub, st)) return e; }
+            else if (int e = gn_hub_gather(g, rows / g->n, 64, Qb[cur], nullptr, hub_scratch, &GQhub, nullptr, st)) return e;
             const int s = slot_of(i - 1);
             const float* gSs = s >= 0 ? gS + (size_t)s * rows : nullptr;
+            auto fused_kernel = two ? k_bwd_fused64<GN_BWD_RPG1_OCC, 1, true> : k_bwd_fused64<GN_BWD_RPG1_OCC, 1, false>;
+            const bool sampled = gn_prof_begin(2, st);
             hipLaunchKernelGGL(fused_kernel, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, tps, total, ZS,
                                ZIb[cur], Qb[cur], ZIb[cur ^ 1], Qb[cur ^ 1], sol + (size_t)i * 4 * slab,
                                sol + (size_t)(i - 1) * 4 * slab, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma,
                                dt_host[i - 1], a, part, gSs, s >= 0 ? gI + (size_t)s * rows : nullptr,
                                s >= 0 ? gR + (size_t)s * rows : nullptr, p->linear3_weight, p->linear3_bias,
-                               p->linearS2_weight, p->linearS2_bias, g->hubidx, AIhub, GQhub, g->n_hub, i > 1 ? 1 : 0);
+                               p->linearS2_weight, p->linearS2_bias, g->hubidx, AIhub, GQhub, g->n_hub, i > 1 ? 1 : 0,
+                               sol + (size_t)i * 4 * slab + 3 * slab);
+            if (sampled) gn_prof_end(2, st);
             GN_LAUNCH_CHECK();
         }
     } else if (H <= 32 && n_steps >= 1) {

@@ -41,6 +41,10 @@ int gn_sir_set_attributes();
 
 void gnode_set_error(const char* fmt, ...);
 
+// opt-in launch profiler (gnode_profile_enable): bracket a launch of `kind` with HIP events when it is sampled
+bool gn_prof_begin(int kind, hipStream_t st);
+void gn_prof_end(int kind, hipStream_t st);
+
 #define GN_CHECK_ARG(cond, ...)                 \
     do {                                        \
         if (!(cond)) {                          \

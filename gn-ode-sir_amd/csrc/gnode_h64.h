@@ -5,7 +5,12 @@
 struct Step64Out {
     float* S; float* I; float* R;   // this step's output rows [rows], or null
     float* sol;                     // sol[g+1] base ([4*rows, 64]), or null
+    float* ai;                      // [rows, 64] receives this step's neighbour sums A Z_I(y_g) (kept for the backward), or null
 };
+
+// True when gnode_forward_f32 (H = 64, trajectory kept) stores A Z_I(y_k) in the 4th slab of sol[k], 1 <= k <= n_steps - 1,
+// instead of the beta-gamma copy; gnode_backward_f32 asks the same question about the `sol` it is handed.
+bool gn_sol_carries_ai(const gnode_graph_s* g, int H, int n_steps, int n_out);
 
 int gn_h64_set_attributes();    // once per device, from gnode_graph_create
 int gn_launch_mlp64(const gnode_graph_s* g, const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st);

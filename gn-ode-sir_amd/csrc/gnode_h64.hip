@@ -152,8 +152,12 @@ __device__ __forceinline__ void mfma_dual16(const float* __restrict__ XA, const 
 #ifndef GN_STEP_OCC
 #define GN_STEP_OCC 4
 #endif
+// workgroups per CU: 4 for inference; the training instance (full Y_R rows, kept neighbour sums) needs ~140 VGPRs, and
+// squeezed into the 128 of four waves per SIMD it spills INSIDE the loop -- a scratch reload is a vector-memory load,
+// waiting for it drains the whole prefetch pipeline -- so it runs 3 per CU (the launch time does not depend on 3 vs 4)
+template <bool PRJ> struct StepOcc { static constexpr int value = PRJ ? GN_STEP_OCC : (GN_STEP_OCC > 3 ? 3 : GN_STEP_OCC); };
 template <bool PRJ>
-__global__ __launch_bounds__(256, GN_STEP_OCC) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+__global__ __launch_bounds__(256, StepOcc<PRJ>::value) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                  long rows, int tiles_per_sample, long total_tiles,
                                                  float* Y, const float* __restrict__ ZI,
                                                  float* __restrict__ ZI_next, const float* __restrict__ W,
@@ -163,6 +167,8 @@ __global__ __launch_bounds__(256, GN_STEP_OCC) void k_step64(const int* __restri
                                                  const float* __restrict__ w2, const float* __restrict__ b2,
                                                  float* __restrict__ PR, Step64Out out,
                                                  const int* __restrict__ hubidx, const float* __restrict__ AIhub, int n_hub) {
+    // out.ai (training): the neighbour sums A Z_I(y_k) of this step are kept for the adjoint backward, which then reads a
+    // row back instead of gathering the table a second time
     // measured on the 75k-node benchmark and fixed: non-temporal streaming state accesses (the gather table keeps the
     // L2) and 8 XCD-affine tile queues.  (Write-through `sc1` state stores, which drop the line from L2: 366 vs 360 us.)
     constexpr bool NT = true;
@@ -337,6 +343,7 @@ __global__ __launch_bounds__(256, GN_STEP_OCC) void k_step64(const int* __restri
             if (cur.valid) {
                 st4so<NT>(YSo, off, ys); st4so<NT>(YIo, off, yi);
                 if (!PRJ) st4so<NT>(YRo, off, yr);
+                if (!PRJ && out.ai) st4so<NT>(out.ai, off, acc);
             }
             if (out.S) {
                 float pS, pI, pR;
@@ -689,7 +696,7 @@ int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, flo
     // persistent grid: GN_STEP_OCC workgroups per CU (measured: 3 / 4 / 5 per CU -> 363 / 360 / 400 us per launch on the
     // 75k graph x 8; shrinking the grid so that every workgroup gets the same number of tiles is slower than filling
     // every slot and accepting a +-1 tile imbalance)
-    const int grid = (int)std::min<long>(total, (long)g->num_cu * GN_STEP_OCC);
+    const int grid = (int)std::min<long>(total, (long)g->num_cu * (PR ? StepOcc<true>::value : StepOcc<false>::value));
     if (PR) hipLaunchKernelGGL(k_step64<true>, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, ZI_next, W,
                                bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, PR,
                                out, g->hubidx, AIhub, g->n_hub);

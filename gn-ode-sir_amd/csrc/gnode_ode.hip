@@ -36,10 +36,11 @@ extern "C" int gnode_version(void) { return 200; }   // 200: workspace sizes tak
 #include <vector>
 struct ProfKind { std::vector<hipEvent_t> ev; size_t used = 0; };
 static bool g_prof_on = false;
-static ProfKind g_prof[2];   // 0 = gather/update kernel, 1 = node-MLP kernel
+static const int kProfKinds = 4;   // 0 = step (gather/update) kernel, 1 = node-MLP kernel, 2 = backward interval kernel, 3 = Monte-Carlo kernel
+static ProfKind g_prof[kProfKinds];
 
 static const int kProfEvery = 8;   // bracket one launch in 8: the events themselves cost GPU time
-static long g_prof_seq[2] = {0, 0};
+static long g_prof_seq[kProfKinds] = {0, 0, 0, 0};
 static bool prof_begin(int kind, hipStream_t st);
 static void prof_mark(int kind, hipStream_t st) {
     if (!g_prof_on) return;
@@ -59,11 +60,29 @@ static bool prof_begin(int kind, hipStream_t st) {
     prof_mark(kind, st);
     return true;
 }
+bool gn_prof_begin(int kind, hipStream_t st) { return prof_begin(kind, st); }      // for the other translation units
+void gn_prof_end(int kind, hipStream_t st) { prof_mark(kind, st); }
 
 extern "C" int gnode_profile_enable(int on) {
-    g_prof_seq[0] = g_prof_seq[1] = 0;
     g_prof_on = on != 0;
-    g_prof[0].used = g_prof[1].used = 0;
+    for (int k = 0; k < kProfKinds; ++k) { g_prof_seq[k] = 0; g_prof[k].used = 0; }
+    return 0;
+}
+
+extern "C" int gnode_profile_read_kind(int32_t kind, double* ms_out, int64_t* launches_out) {
+    GN_CHECK_ARG(kind >= 0 && kind < kProfKinds, "gnode_profile_read_kind: kind %d out of range", kind);
+    double ms = 0.0;
+    int64_t cnt = 0;
+    ProfKind& pk = g_prof[kind];
+    for (size_t i = 0; i + 1 < pk.used; i += 2) {
+        GN_HIP(hipEventSynchronize(pk.ev[i + 1]));
+        float t = 0.f;
+        GN_HIP(hipEventElapsedTime(&t, pk.ev[i], pk.ev[i + 1]));
+        ms += t;
+        cnt += 1;
+    }
+    if (ms_out) *ms_out = ms;
+    if (launches_out) *launches_out = cnt;
     return 0;
 }
 
@@ -698,8 +717,11 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         // with a trajectory the fused kernels read point k and write point k+1 (no separate state copy)
         float* Ycur = (sol && (h64 || (method == 0 && H <= 128))) ? sol + (size_t)k * 4 * slab : Y;
         if (h64) {
+            // training: the 4th slab of sol[k] (k >= 1; its odeint content is the constant beta-gamma slab of sol[0])
+            // receives A Z_I(y_k), which the adjoint backward would otherwise gather again
             Step64Out out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
-                             slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
+                             slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next,
+                             (sol && k >= 1) ? sol + (size_t)k * 4 * slab + 3 * slab : nullptr};
             const bool sampled = prof_begin(0, st);
             if (int e = gn_launch_step64(g, rows, Ycur, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,
                                          gamma, dt, p, PR, out, hub_scratch, st))
@@ -757,10 +779,19 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
                     return e;
         }
     }
-    if (sol && n_steps > 0) {
+    if (sol && n_steps > 0 && !h64) {        // (H = 64: those slabs hold A Z_I(y_k) instead, see above)
         const size_t slab4 = slab / 4;
         hipLaunchKernelGGL(k_fill_bg, dim3((unsigned)std::min<size_t>((slab4 + 255) / 256, 2048)), dim3(256), 0, st, sol, slab4, G);
         GN_LAUNCH_CHECK();
     }
     return 0;
+}
+
+bool gn_sol_carries_ai(const gnode_graph_s* g, int H, int n_steps, int n_out) {
+    return H == 64 && n_steps >= 1 && !gn_tiny64_ok(g->n, n_steps, n_out, false);
+}
+
+extern "C" int gnode_sol_carries_neighbour_sums(gnode_graph_t g, int32_t H, int32_t n_steps, int32_t n_out) {
+    if (!g) return 0;
+    return gn_sol_carries_ai(g, H, n_steps, n_out) ? 1 : 0;
 }

@@ -284,6 +284,7 @@ extern "C" int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, i
     const unsigned long long tg = (unsigned long long)std::min(4294967296.0, std::max(0.0, std::floor(gamma * 4294967296.0)));
     const uint32_t k0 = (uint32_t)(rng_seed & 0xFFFFFFFFull), k1 = (uint32_t)(rng_seed >> 32);
     if (sims > 0) {
+        const bool sampled = gn_prof_begin(3, st);
         const size_t lds = (size_t)2 * g->n;
         if (lds <= kLdsStateLimit) {
             // workgroups per CU by LDS; keep >= 16 waves per CU: big states get 1024-thread workgroups
@@ -297,6 +298,7 @@ extern "C" int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, i
             hipLaunchKernelGGL(k_sir_philox<false>, dim3(grid), dim3(256), 0, st, src, g->col, (long)g->nnz, g->n, seeds,
                                n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, gstate);
         }
+        if (sampled) gn_prof_end(3, st);
         GN_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_sir_finalize, dim3((g->n + 255) / 256), dim3(256), 0, st, hist, g->n, T, (uint32_t)sims, counts);

@@ -17,13 +17,13 @@ EXPORTS = [
     "gnode_last_error", "gnode_version",
     "gnode_graph_create", "gnode_graph_destroy", "gnode_graph_info",
     "gnode_rhs_workspace_bytes", "gnode_rhs_f32",
-    "gnode_forward_workspace_bytes", "gnode_forward_f32",
+    "gnode_forward_workspace_bytes", "gnode_forward_f32", "gnode_sol_carries_neighbour_sums",
     "gnode_backward_workspace_bytes", "gnode_backward_f32",
     "gnode_sir_workspace_bytes", "gnode_sir_coins_workspace_bytes",
     "gnode_sir_mc_philox", "gnode_sir_mc_coins",
     "gnode_dmp_workspace_bytes", "gnode_dmp_f32",
     "gnode_meanfield_workspace_bytes", "gnode_meanfield_f64",
-    "gnode_profile_enable", "gnode_profile_read",
+    "gnode_profile_enable", "gnode_profile_read", "gnode_profile_read_kind",
 ]
 
 
@@ -66,6 +66,8 @@ def load():
     lib.gnode_rhs_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, sz, vp]
     lib.gnode_forward_workspace_bytes.argtypes = [vp, i64, i32, i32]
     lib.gnode_forward_workspace_bytes.restype = sz
+    lib.gnode_sol_carries_neighbour_sums.argtypes = [vp, i32, i32, i32]
+    lib.gnode_sol_carries_neighbour_sums.restype = C.c_int
     lib.gnode_forward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp, sz, vp]
     lib.gnode_meanfield_workspace_bytes.argtypes = [vp]
     lib.gnode_meanfield_workspace_bytes.restype = sz
@@ -87,6 +89,7 @@ def load():
                                        C.POINTER(i64), vp, sz, vp]
     lib.gnode_profile_enable.argtypes = [C.c_int]
     lib.gnode_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64)]
+    lib.gnode_profile_read_kind.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(i64)]
     for fn in ("gnode_graph_create", "gnode_graph_destroy", "gnode_graph_info", "gnode_rhs_f32", "gnode_forward_f32",
                "gnode_sir_mc_philox", "gnode_sir_mc_coins"):
         getattr(lib, fn).restype = C.c_int

@@ -31,8 +31,6 @@ class _GNODEForward(torch.autograd.Function):
         params = dict(zip(ctx.keys, tensors))
         ref = next(g for g in (gS, gI, gR) if g is not None)          # an output the loss did not use has no gradient
         gS, gI, gR = (torch.zeros_like(ref) if g is None else g for g in (gS, gI, gR))
-        if not hasattr(ops, "backward"):
-            raise NotImplementedError("GN-ODE adjoint backward is not built in this revision")
         grads = ops.backward(ctx.graph, x2d, params, ctx.dts, ctx.method, ctx.out_rows, sol,
                              gS.contiguous(), gI.contiguous(), gR.contiguous())
         return (None, None, None, None, None, None, *[grads[k] for k in ctx.keys])

@@ -9,9 +9,13 @@ A batch concatenates samples of different graphs along the node axis
 column 2 of the beta-gamma slab at the sample's first node (:55, :333).  The
 reference re-reads that marker on the host and rebuilds a scipy block_diag on
 EVERY RHS call (:65-71); here it is read once per forward and the concatenated
-CSR is cached on the GPU per batch composition.
+CSR is cached on the GPU per batch composition (LRU, bounded; the trainer keeps
+the reference's fixed batches -- shuffled once, ode_nn_ngraphs.py:359 -- so a
+training run touches one composition per batch, not one per batch per epoch).
 """
 from __future__ import annotations
+
+import collections
 
 import torch
 import torch.nn as nn
@@ -27,7 +31,8 @@ class ODEfunc(nn.Module):
         self.ln = nn.LayerNorm(hidden1)             # unused in the reference forward; state_dict parity
         self.linear = nn.Linear(hidden1, hidden1)
         self._csr = [csr_arrays(A) for A in A_list]
-        self._cache = {}
+        self._cache = collections.OrderedDict()      # batch composition -> DeviceGraph, least recently used first
+        self.cache_limit = 256                       # evicted handles are destroyed (their HBM goes back) when unreferenced
 
     def init_weights(self):
         """reference :57-58 (defined, never called)."""
@@ -41,6 +46,10 @@ class ODEfunc(nn.Module):
         if g is None:
             g = DeviceGraph(*concat_csr([self._csr[p] for p in picks]))
             self._cache[picks] = g
+            while len(self._cache) > self.cache_limit:
+                self._cache.popitem(last=False)
+        else:
+            self._cache.move_to_end(picks)
         return g
 
     def forward(self, t, x):

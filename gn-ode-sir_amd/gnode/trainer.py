@@ -61,8 +61,14 @@ def load_SIR_labels(dataset, path_to_save, G, I_indices, beta, gamma, sim, maxTi
     Under torch.distributed this is a COLLECTIVE: the `sim` trajectories are split over the ranks
     (coins are keyed by the global trajectory index), the uint32 [3,T,n] counts are all-reduced
     once per sample, and rank 0 writes the cache."""
+    return _label_store(label_paths(dataset, path_to_save, I_indices), G, I_indices, beta, gamma, sim, maxTime, False)
+
+
+def _label_store(ps, G, I_indices, beta, gamma, sim, maxTime, raw_counts):
+    """Load-or-generate behind both label conventions.  raw_counts=False: files hold probabilities (single-graph
+    script, ode_nn_ngraph_sim.py:190-206); raw_counts=True: files hold COUNTS and the loader divides by `sim`
+    (the multi-graph script's wiki-vote convention, ode_nn_ngraphs.py:168-171).  Returns probabilities."""
     rank, world = sharding.world_info()
-    ps = label_paths(dataset, path_to_save, I_indices)
     have = os.path.exists(ps[0])
     coll = sharding.collectives_on()
     if coll:
@@ -71,10 +77,11 @@ def load_SIR_labels(dataset, path_to_save, G, I_indices, beta, gamma, sim, maxTi
         torch.distributed.broadcast(flag, src=0)
         have = bool(flag.item())
     if have:
-        return tuple(pickle.load(open(p, "rb")) for p in ps)
+        out = tuple(pickle.load(open(p, "rb")) for p in ps)
+        return tuple(a / sim for a in out) if raw_counts else out
     if not coll:
         S, I, R = sir_torch(G, I_indices, beta, gamma, sim, maxTime)
-        out = (S[0] / sim, I[0] / sim, R[0] / sim)
+        cnt = (S[0], I[0], R[0])
     else:
         from .ode_nn import _device_graph_for, sir_counts
         seed = torch.randint(0, 2**62, (1,), dtype=torch.int64).to(dev)
@@ -84,9 +91,10 @@ def load_SIR_labels(dataset, path_to_save, G, I_indices, beta, gamma, sim, maxTi
         counts = sir_counts(graph, I_indices, beta, gamma, hi - lo, maxTime, int(seed.item()), sim_offset=lo)
         sharding.allreduce_counts(counts)
         c = (counts.cpu().numpy().astype(np.int64) & 0xFFFFFFFF).astype(np.float64)
-        out = (c[0] / sim, c[1] / sim, c[2] / sim)
+        cnt = (c[0], c[1], c[2])
+    out = tuple(a / sim for a in cnt)
     if rank == 0:
-        for p, a in zip(ps, out):
+        for p, a in zip(ps, cnt if raw_counts else out):
             pickle.dump(a, open(p, "wb"))
     sharding.barrier()
     return out
@@ -166,6 +174,9 @@ class Runner:
         return tuple([t.to(self.device) for t in l] for l in lists)
 
     def batches(self, n_items, batch_size, shuffle, epoch=0):
+        if shuffle and not self.stack:
+            epoch = 0      # multi-graph: the reference shuffles ONCE, before the epoch loop (ode_nn_ngraphs.py:179-196, :359),
+                           # and reuses those batches -- which also keeps the per-composition device graphs few and reusable
         if shuffle:
             g = torch.Generator().manual_seed(self.seed + epoch)       # same permutation on every rank
             idx = torch.randperm(n_items, generator=g).tolist()
@@ -425,17 +436,52 @@ def parser_multi():
     p.add_argument("--model", default="ode_nn", type=str)
     p.add_argument("--instances_per_graph", type=int, nargs="+", default=[36, 36, 36, 36, 36, 120],
                    help="extension: the reference hard-codes this list (ode_nn_ngraphs.py:311)")
+    p.add_argument("--standin", type=int, nargs=2, default=[75000, 500000], metavar=("N", "M"),
+                   help="extension: nodes / undirected edges of the Erdos-Renyi stand-in used for a graph pickle that is "
+                        "missing (the reference does not ship epinions.pkl)")
     p.add_argument("--per_sample_seeds", action="store_true",
                    help="extension: use each sample's own seed set; the reference infects ALL sampled seeds of a graph "
                         "in every sample (quirk Q5, ode_nn_ngraphs.py:343), which stays the default")
     return p
 
 
-def load_multi_labels(dataset, path_to_save, I_indices, sim):
-    """ode_nn_ngraphs.py:167-177: labels are only loaded; wiki-vote files hold raw counts."""
-    div = sim if dataset == "wiki-vote" else 1
+def load_multi_labels(dataset, path_to_save, I_indices, sim, G=None, beta=None, gamma=None, maxTime=None):
+    """ode_nn_ngraphs.py:167-177 reads label files only (wiki-vote's hold raw counts, divided by `sim` on load) and the
+    reference ships karate's alone.  Extension: a missing label set is generated with the
+    Monte-Carlo kernel -- sharded over the ranks like the single-graph script's -- and written under the same names
+    and conventions, so a clean experiment directory works."""
     stem = path_to_save + "/" + dataset + "-{}-" + "-".join(str(i) for i in I_indices) + ".pkl"
-    return tuple(pickle.load(open(stem.format(c), "rb")) / div for c in "SIR")
+    ps = [stem.format(c) for c in "SIR"]
+    if G is None and not os.path.exists(ps[0]):
+        raise FileNotFoundError(ps[0])
+    return _label_store(ps, G, I_indices, beta, gamma, sim, maxTime, raw_counts=(dataset == "wiki-vote"))
+
+
+def standin_graph(name, n, m, seed=0):
+    """Synthetic stand-in for a graph pickle the reference does not ship (`epinions.pkl`, .MISSING_LARGE_BLOBS):
+    Erdos-Renyi G(n, m) with the node / edge counts asked for.  Returns (G, A, 0) like create_graph."""
+    import scipy.sparse as sp
+    from . import synth
+    from .ode_nn import CsrGraph
+    rp, ci = synth.er_csr(n, m, seed=seed)
+    A = sp.csr_matrix((np.ones(ci.shape[0], dtype=np.int64), ci, rp), shape=(n, n))
+    coo = sp.triu(A, k=1).tocoo()
+    print(f"[gnode] {name}.pkl is not there: using a synthetic Erdos-Renyi stand-in G({n}, {m})")
+    return CsrGraph(n, np.stack([coo.row, coo.col], 1)), A, 0
+
+
+def ensure_initial_files(d, n_nodes, count, n_seeds):
+    """`initial-{seed,beta,gamma}.pkl` of an experiment directory (written by monitorer-sim.py:209-226 runs in the
+    reference's workflow): when absent, sample them as random_parameters_SIR does (monitorer-sim.py:105-121) --
+    `n_seeds` distinct seed nodes, beta and gamma ~ U(0.1, 0.5) per sample -- on rank 0, and write them."""
+    rank, _ = sharding.world_info()
+    if rank == 0 and not os.path.exists(d + "/initial-seed.pkl"):
+        os.makedirs(d, exist_ok=True)
+        seeds = [[int(v) for v in np.random.choice(n_nodes, n_seeds, replace=False)] for _ in range(count)]
+        pickle.dump(seeds, open(d + "/initial-seed.pkl", "wb"))
+        pickle.dump([float(np.random.uniform(0.1, 0.5)) for _ in range(count)], open(d + "/initial-beta.pkl", "wb"))
+        pickle.dump([float(np.random.uniform(0.1, 0.5)) for _ in range(count)], open(d + "/initial-gamma.pkl", "wb"))
+    sharding.barrier()
 
 
 def main_multi(argv=None):
@@ -446,10 +492,15 @@ def main_multi(argv=None):
         raise SystemExit(f"this entry point serves model='ode_nn' only (got {args.model!r})")
     rank, world = sharding.init_from_env()
     names = args.dataset[14:].split("+")
-    A_list = []
+    A_list, G_list = [], []
     for gname in names:                                             # create_graphs, ode_nn_ngraphs.py:154-165
-        _, A, _ = create_graph(0, args.dataset[:14] + gname, cache=os.environ.get("GNODE_GRAPH_CACHE", "0") == "1")
+        label = args.dataset[:14] + gname
+        if os.path.exists(label + ".pkl"):
+            G, A, _ = create_graph(0, label, cache=os.environ.get("GNODE_GRAPH_CACHE", "0") == "1")
+        else:
+            G, A, _ = standin_graph(gname, args.standin[0], args.standin[1])
         A_list.append(A)
+        G_list.append(G)
     print(len(A_list))
     ipg = args.instances_per_graph
     n_train_graphs = len(ipg) - 2
@@ -465,12 +516,14 @@ def main_multi(argv=None):
             last = args.path_to_save.split("/")[-1].split("-")
             path_load = "./multi-graph-1/" + last[0] + "-" + last[1]
         d = path_load + "-" + gname
+        n_nodes = A_list[gi].shape[0]
+        digits = "".join(ch for ch in path_load.split("seed")[-1] if ch.isdigit())       # "...-seed2" -> 2 seeds per sample
+        ensure_initial_files(d, n_nodes, ipg[gi], int(digits) if digits else 2)
         I_all = pickle.load(open(d + "/initial-seed.pkl", "rb"))[:ipg[gi]]
         betas = pickle.load(open(d + "/initial-beta.pkl", "rb"))[:ipg[gi]]
         gammas = pickle.load(open(d + "/initial-gamma.pkl", "rb"))[:ipg[gi]]
-        n_nodes = A_list[gi].shape[0]
         for i, indices in enumerate(I_all):
-            S, I, R = load_multi_labels(gname, d, indices, args.sim)
+            S, I, R = load_multi_labels(gname, d, indices, args.sim, G_list[gi], betas[i], gammas[i], args.maxTime)
             y = torch.from_numpy(np.stack([np.asarray(S), np.asarray(I), np.asarray(R)], -1)).transpose(0, 1).contiguous()
             seeds = indices if args.per_sample_seeds else [s for grp in I_all for s in (grp if isinstance(grp, (list, tuple)) else [grp])]
             x = sample_tensor(n_nodes, args.hidden, seeds, betas[i], gammas[i], marker=gi + 1)

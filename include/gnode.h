@@ -102,9 +102,20 @@ int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* 
  *                  n_steps+1 points (n_out ignored)
  *   S, I, R    device [n_out, rows] each (the reference's [G, rows, 1])
  *   sol        NULL, or device [n_steps+1, 4*rows, H]: the trajectory odeint
- *              returns (needed by the adjoint backward, never by inference)
+ *              returns (needed by the adjoint backward, never by inference).
+ *              Slabs S, I, R of every grid point are odeint's.  The 4th slab
+ *              (beta, gamma; derivative 0, so odeint repeats sol[0]'s at every grid
+ *              point) is odeint's at grid point 0 everywhere; at H = 64 (the fused
+ *              path, graphs that do not fit the one-launch kernel) grid points
+ *              1 .. n_steps-1 carry A*Z_I(y_k) there instead -- the neighbour sums
+ *              the adjoint backward would otherwise gather a second time -- and the
+ *              last grid point's is left unwritten; other H repeat beta, gamma.
  *   workspace  device, >= gnode_forward_workspace_bytes(g, rows, H, method) */
 size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t method);
+/* 1 when gnode_forward_f32 (method 0) on this graph stores A*Z_I(y_k) in the 4th slab of sol[k], 1 <= k <= n_steps-1
+ * (see `sol` below), 0 when the 4th slab repeats beta, gamma at every grid point.  n_out: number of emitted grid
+ * points (n_steps+1 when out_rows_host is NULL). */
+int gnode_sol_carries_neighbour_sums(gnode_graph_t g, int32_t H, int32_t n_steps, int32_t n_out);
 int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
                       int32_t n_steps, int32_t method, const int32_t* out_rows_host, int32_t n_out,
                       float* S, float* I, float* R, float* sol, int64_t rows, int32_t H,
@@ -114,7 +125,8 @@ int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, co
  * The gradient the reference trains with: torchdiffeq's odeint_adjoint under
  * method='euler' (imported at ode_nn_ngraph_sim.py:16, called at :168; semantics in
  * SURVEY Appendix A) followed by autograd through the head and the encoder.
- *   sol          device [n_steps+1, 4*rows, H] saved by gnode_forward_f32
+ *   sol          device [n_steps+1, 4*rows, H] saved by gnode_forward_f32 on THIS graph with the
+ *                same n_steps / out_rows (its 4th slabs are read as described there)
  *   gS, gI, gR   device [n_out, rows] upstream gradients of the outputs
  *   grads        device pointers (same struct as the parameters) that RECEIVE
  *                dL/dparam (overwritten, not accumulated)
@@ -196,6 +208,9 @@ int gnode_meanfield_f64(gnode_graph_t g, const int32_t* seeds_host, int32_t n_se
  * Process-wide and not thread-safe: switch it on around a single-threaded region. */
 int gnode_profile_enable(int on);
 int gnode_profile_read(double* gather_ms, int64_t* gather_launches, double* mlp_ms, int64_t* mlp_launches);
+/* kind: 0 = Euler-step kernel, 1 = node-MLP kernel, 2 = backward interval kernel (H = 64), 3 = Monte-Carlo kernel;
+ * one launch in 8 is sampled (the first of every 8 of its kind since gnode_profile_enable(1)). */
+int gnode_profile_read_kind(int32_t kind, double* ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

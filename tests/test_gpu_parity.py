@@ -200,7 +200,10 @@ def test_forward_vs_oracle(n, m, B, H, maxTime, deltaT, method, dev):
 
 
 def test_forward_sol_matches_states(dev):
-    """sol (what odeint returns) is consistent with the fused outputs and with the oracle."""
+    """sol (what odeint returns) is consistent with the fused outputs and with the oracle.  Slabs S, I, R: every grid
+    point.  4th slab: grid point 0 carries beta / gamma as odeint's y0 does; its derivative is 0, so odeint repeats it
+    at every grid point -- the H = 64 training forward uses those copies (1 <= k <= n_steps - 1) to keep A Z_I(y_k) for
+    the adjoint backward instead (include/gnode.h), which is checked here against the oracle's own A Z_I."""
     import torch
     import gnode_oracle as O
     from gnode import ops
@@ -214,8 +217,24 @@ def test_forward_sol_matches_states(dev):
                                ops.step_sizes(ops.time_grid(5, 0.5)), want_sol=True)
     So, Io, Ro, sol_o = O.odeblock_forward_single(x, P, rp, ci, 5, 0.5, return_sol=True)
     assert tuple(sol.shape) == sol_o.shape
-    assert _rel(sol.cpu().numpy(), sol_o) <= RTOL
-    assert np.array_equal(sol[:, 3 * B * n:].cpu().numpy(), sol_o[:, 3 * B * n:])   # beta-gamma slab rides along
+    q = 3 * B * n
+    sol_h = sol.cpu().numpy()
+    assert _rel(sol_h[:, :q], sol_o[:, :q]) <= RTOL
+    assert np.array_equal(sol_h[0, q:], sol_o[0, q:])                       # beta-gamma slab of y0
+    G = sol_o.shape[0]
+    for k in range(1, G - 1):                                               # kept neighbour sums A Z_I(y_k)
+        yI = sol_o[k, B * n:2 * B * n].astype(np.float64)
+        zI = 1.0 / (1.0 + np.exp(-(yI @ P["odefunc.linear.weight"].T.astype(np.float64) + P["odefunc.linear.bias"])))
+        AI = O._spmm_blockdiag(rp, ci, n, zI.astype(np.float32))
+        assert _rel(sol_h[k, q:], AI) <= RTOL
+    # generic hidden size: the 4th slab is odeint's (the beta-gamma slab rides along at every grid point)
+    H2 = 16
+    P2 = O.init_params(H2, seed=3)
+    x2 = O.make_samples(n, B, H2, seed=1)
+    _, _, _, sol2 = ops.forward(g, torch.from_numpy(x2).to(dev).reshape(B * n, 3 + H2), _tp(P2, dev),
+                                ops.step_sizes(ops.time_grid(5, 0.5)), want_sol=True)
+    sol2_o = O.odeblock_forward_single(x2, P2, rp, ci, 5, 0.5, return_sol=True)[3]
+    assert np.array_equal(sol2[:, q:].cpu().numpy(), sol2_o[:, q:])
 
 
 def test_block_diagonal_independence(dev):
@@ -568,7 +587,13 @@ def test_randomized_configurations(dev):
             assert tuple(got.shape) == (len(idx), B * n), tag
             assert _rel(got.cpu().numpy(), w[idx, :, 0]) <= RTOL, tag
         if want_sol:
-            assert _rel(sol.cpu().numpy(), sol_o) <= RTOL, tag
+            from gnode import _lib
+            q, sol_h = 3 * B * n, sol.cpu().numpy()
+            assert _rel(sol_h[:, :q], sol_o[:, :q]) <= RTOL, tag
+            assert np.array_equal(sol_h[0, q:], sol_o[0, q:]), tag
+            carries = _lib.load().gnode_sol_carries_neighbour_sums(g.handle, H, G - 1, len(idx)) if method == "euler" else 0
+            if not carries:      # odeint's own 4th slab at every grid point (the fused H = 64 path keeps A Z_I there instead:
+                assert np.array_equal(sol_h[:, q:], sol_o[:, q:]), tag      # test_forward_sol_matches_states)
 
 
 @pytest.mark.parametrize("name", ["karate", "er120", "loops40"])

@@ -105,6 +105,52 @@ def test_multi_graph_entry_point(tmp_path, monkeypatch, dev):
     assert len(df) == 1 and np.isfinite(df["test_loss"][0])
 
 
+def test_multi_graph_entry_point_from_empty_directory(tmp_path, monkeypatch, dev):
+    """the multi-graph script from a CLEAN multi-graph-1/ (the reference ships karate's labels
+    only and no epinions.pkl): `initial-*.pkl` sampled as monitorer-sim's random_parameters_SIR does, every label set
+    generated with the Monte-Carlo kernel and written under the reference's names and conventions (probabilities;
+    raw counts for wiki-vote, ode_nn_ngraphs.py:168-171), the missing graph pickle replaced by a synthetic stand-in;
+    a second run finds everything in place and reuses it."""
+    import pandas as pd
+    from gnode.trainer import main_multi
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("real_graphs")
+    G1 = _mk_graph("real_graphs/ga.pkl", 40, 100, 5)
+    G2 = _mk_graph("real_graphs/wiki-vote.pkl", 60, 200, 6)           # the name selects the raw-count convention
+    ipg, sim, T = [2, 3, 4], 50, 5                                    # train: ga, wiki-vote ; val 2 + test 2 from epinions
+    save = "./multi-graph-1/Experiments-seed2-ga+wiki-vote+epinions"
+    os.makedirs(save)
+    argv = ["--lr", "0.01", "--epochs", "2", "--hidden", "8", "--deltaT", "0.5", "--maxTime", str(T), "--sim", str(sim),
+            "--trial", "0", "--dataset", "./real_graphs/ga+wiki-vote+epinions", "--path_to_save", save,
+            "--batch_size", "2", "--train_val_test_ratio", "0.6", "0.2", "0.2", "--model", "ode_nn",
+            "--standin", "90", "300", "--instances_per_graph"] + [str(v) for v in ipg]
+    assert main_multi(argv) == 0
+    dirs = {"ga": "multi-graph-1/Experiments-seed2-ga", "wiki-vote": "multi-graph-1/Experiments-gpu-seed2-wiki-vote",
+            "epinions": "multi-graph-1/Experiments-seed2-epinions"}
+    nodes = {"ga": G1.number_of_nodes(), "wiki-vote": G2.number_of_nodes(), "epinions": 90}
+    stamp = {}
+    for (name, d), k in zip(dirs.items(), ipg):
+        seeds = pickle.load(open(d + "/initial-seed.pkl", "rb"))
+        betas = pickle.load(open(d + "/initial-beta.pkl", "rb"))
+        assert len(seeds) == k and all(len(s) == 2 and len(set(s)) == 2 for s in seeds)
+        assert all(0.1 <= b <= 0.5 for b in betas)
+        for s in seeds:
+            arrs = [pickle.load(open(f"{d}/{name}-{c}-{s[0]}-{s[1]}.pkl", "rb")) for c in "SIR"]
+            tot = arrs[0] + arrs[1] + arrs[2]
+            assert arrs[0].shape == (T, nodes[name]) and arrs[0].dtype == np.float64
+            if name == "wiki-vote":                                   # raw counts; the loader divides by sim
+                assert np.all(tot[1:] == sim) and np.all(arrs[0] == np.round(arrs[0]))
+            else:
+                assert np.allclose(tot[1:], 1.0) and arrs[0].max() <= 1.0
+            stamp[f"{d}/{name}-S-{s[0]}-{s[1]}.pkl"] = os.path.getmtime(f"{d}/{name}-S-{s[0]}-{s[1]}.pkl")
+    df = pd.read_csv(save + "/Metrics-trials-ga+wiki-vote+epinions")
+    assert len(df) == 1 and np.isfinite(df["test_loss"][0]) and np.isfinite(df["val_loss"][0])
+    argv[argv.index("--trial") + 1] = "1"
+    assert main_multi(argv) == 0                                      # everything is reused, nothing regenerated
+    assert all(os.path.getmtime(p) == t for p, t in stamp.items())
+    assert len(pd.read_csv(save + "/Metrics-trials-ga+wiki-vote+epinions")) == 2
+
+
 def test_graph_replay_equals_eager(dev):
     """HIP-graph replay of (forward + L1 + adjoint backward) gives bit-identical training to eager launches."""
     import copy
