@@ -6,13 +6,18 @@
 // gamma, both decided on the pre-step state (:60-78); per-(t, node) membership
 // counts are accumulated (:80-82) with row 0 ASSIGNED (:55-56).
 //
-// The reference runs ~20 torch launches and >= 4 host syncs per (sim, step).
-// Here one workgroup owns one trajectory with its node state in LDS (1 byte per
-// node), scans the directed edge list cooperatively, and records only the two
-// EVENTS a node can have (infection step, recovery step) with integer atomics;
-// a final pass turns the event histograms into the S/I/R counts by a prefix sum
-// over time.  All arithmetic is integer: results are bit-exact and independent
-// of scheduling.
+// The reference runs ~20 torch launches and >= 4 host syncs per (sim, step) and tests EVERY directed edge
+// against the infected set each step (`isin` over all 2E rows, ode_nn.py:61).  Here one workgroup owns one
+// trajectory and keeps its FRONTIER -- the list of currently infected nodes -- next to an "ever infected" bitmap in
+// LDS; a step walks only the CSR rows of the listed nodes (one 16-lane group per node, very long rows by the whole
+// workgroup), draws the recovery coin of each listed node, and builds the next list in the same pass: work per
+// step is the frontier's out-degree, not nnz (k_sir_frontier).  Only the two EVENTS a node can have (infection
+// step, recovery step) reach memory, as integer atomics; a final pass turns the event histograms into the S/I/R
+// counts by a prefix sum over time.  Coins are Philox4x32-10 keyed (CSR position | node, step, trajectory, kind),
+// so which edges are visited, in which order, by which lane, or on which GPU cannot change a count: all arithmetic
+// is integer, results are bit-exact against the edge-scan statement of the same model (oracle: sir_philox; the
+// edge-parallel kernel k_sir_philox below remains for graphs whose lists do not fit and as the in-library
+// cross-check of the tests).
 #include "gnode_common.h"
 #include <algorithm>
 
@@ -105,6 +110,94 @@ __global__ __launch_bounds__(1024) void k_sir_philox(const int* __restrict__ src
             if (!__syncthreads_or(any)) break;      // epidemic over: no further events in this trajectory
         }
         __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------- frontier-driven kernel
+// LDS: ever-infected bitmap (n bits) and, when they fit (uint16 ids: n up to ~25 000 -- every graph of the reference's
+// multi-graph experiment but enron and epinions), the node lists: current / next frontier and the rows too long for
+// one lane group.  Larger graphs keep the three lists in the caller's workspace (int32 ids, one set per workgroup).
+#ifndef GN_SIR_BIGROW
+#define GN_SIR_BIGROW 512     // rows longer than this are walked by the whole workgroup
+#endif
+template <typename IdT, bool LISTS_IN_LDS>
+__global__ __launch_bounds__(1024) void k_sir_frontier(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+                                                      const int* __restrict__ seeds, int n_seeds,
+                                                      unsigned long long thr_beta, unsigned long long thr_gamma,
+                                                      long sims, long sim_offset, int T, uint32_t k0, uint32_t k1,
+                                                      uint32_t* __restrict__ hist, int32_t* __restrict__ glists) {
+    extern __shared__ uint32_t smem_w[];
+    const int nwords = (n + 31) >> 5;
+    uint32_t* bits = smem_w;                                   // ever infected (seeds included): susceptible <=> bit clear
+    IdT* lists = LISTS_IN_LDS ? reinterpret_cast<IdT*>(smem_w + ((nwords + 3) & ~3))
+                              : reinterpret_cast<IdT*>(glists + (size_t)blockIdx.x * 3 * n);
+    IdT* cur = lists;
+    IdT* nxt = lists + n;
+    IdT* big = lists + 2 * (size_t)n;                          // [n] (worst case: every frontier row is long)
+    __shared__ int cnt[3];                                     // [0] next-list length, [1] big-row list length, [2] ever infected
+    uint32_t* hinf = hist;
+    uint32_t* hrec = hist + (size_t)T * n;
+    const int nthr = blockDim.x, tid = threadIdx.x;
+    const int sub = tid & 15, gid = tid >> 4, ngroups = nthr >> 4;
+    for (long s = blockIdx.x; s < sims; s += gridDim.x) {
+        const uint32_t sim = (uint32_t)(sim_offset + s);
+        for (int w = tid; w < nwords; w += nthr) bits[w] = 0u;
+        if (tid < 3) cnt[tid] = 0;
+        __syncthreads();
+        for (int j = tid; j < n_seeds; j += nthr) {            // distinct seeds: one infection event at t = 0 each
+            const int v = seeds[j];
+            const uint32_t m = 1u << (v & 31);
+            if (!(atomicOr(&bits[v >> 5], m) & m)) { cur[atomicAdd(&cnt[0], 1)] = (IdT)v; atomicAdd(&hinf[v], 1u); }
+        }
+        __syncthreads();
+        int n_inf = cnt[0];
+        int n_ever = n_inf;                                    // once it reaches n nobody is left to infect: recovery coins only
+        __syncthreads();
+        if (tid == 0) cnt[2] = n_ever;
+        for (int it = 1; it < T && n_inf > 0; ++it) {
+            if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+            __syncthreads();
+            // infection attempts along the out-edges of the frontier: one 16-lane group per infected node
+            auto try_edge = [&](int e) {
+                const int v = col[e];
+                const uint32_t m = 1u << (v & 31);
+                if (!(bits[v >> 5] & m) &&
+                    (unsigned long long)philox_word0((uint32_t)e, (uint32_t)it, sim, 0u, k0, k1) < thr_beta) {
+                    if (!(atomicOr(&bits[v >> 5], m) & m)) {   // first edge to reach v this step (it was susceptible)
+                        nxt[atomicAdd(&cnt[0], 1)] = (IdT)v;
+                        atomicAdd(&cnt[2], 1);
+                        atomicAdd(&hinf[(size_t)it * n + v], 1u);
+                    }
+                }
+            };
+            if (n_ever < n)
+            for (int idx = gid; idx < n_inf; idx += ngroups) {
+                const int u = (int)cur[idx];
+                const int lo = rowptr[u], hi = rowptr[u + 1];
+                if (hi - lo > GN_SIR_BIGROW) { if (sub == 0) big[atomicAdd(&cnt[1], 1)] = (IdT)u; continue; }
+                for (int e = lo + sub; e < hi; e += 16) try_edge(e);
+            }
+            // recovery coin of every node of the frontier (decided on the pre-step state: a node infected in this step is
+            // not on `cur`); survivors go on the next list
+            for (int idx = tid; idx < n_inf; idx += nthr) {
+                const int u = (int)cur[idx];
+                if ((unsigned long long)philox_word0((uint32_t)u, (uint32_t)it, sim, 1u, k0, k1) < thr_gamma)
+                    atomicAdd(&hrec[(size_t)it * n + u], 1u);
+                else
+                    nxt[atomicAdd(&cnt[0], 1)] = (IdT)u;
+            }
+            __syncthreads();
+            const int n_big = cnt[1];
+            for (int b = 0; b < n_big; ++b) {                   // hub rows: the whole workgroup strides one row
+                const int u = (int)big[b];
+                for (int e = rowptr[u] + tid; e < rowptr[u + 1]; e += nthr) try_edge(e);
+            }
+            __syncthreads();
+            n_inf = cnt[0];
+            n_ever = cnt[2];
+            IdT* t = cur; cur = nxt; nxt = t;
+            __syncthreads();
+        }
     }
 }
 
@@ -227,7 +320,15 @@ __global__ void k_put_seeds(SeedArg sa, int n_seeds, int32_t* __restrict__ seeds
     if ((int)threadIdx.x < n_seeds) seeds[threadIdx.x] = sa.v[threadIdx.x];
 }
 
+// LDS of the frontier kernel: bitmap (+ three uint16 node lists -- current, next, long rows -- when they fit)
+static size_t frontier_bitmap_bytes(int n) { return ((((size_t)n + 31) / 32 + 3) & ~(size_t)3) * 4; }
+static bool frontier_lists_in_lds(int n) { return n <= 65536 && frontier_bitmap_bytes(n) + 6 * (size_t)n <= 48 * 1024; }
+static size_t frontier_lds_bytes(int n) { return frontier_bitmap_bytes(n) + (frontier_lists_in_lds(n) ? 6 * (size_t)n : 0); }
+static const int kFrontierGlobalGrid = 1024;       // workgroups that own a set of global lists (graphs past the LDS form)
+
 int gn_sir_set_attributes() {       // once per device, from gnode_graph_create
+    GN_HIP(hipFuncSetAttribute((const void*)k_sir_frontier<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
+    GN_HIP(hipFuncSetAttribute((const void*)k_sir_frontier<int32_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
     GN_HIP(hipFuncSetAttribute((const void*)k_sir_philox<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
     GN_HIP(hipFuncSetAttribute((const void*)k_sir_coins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
     return 0;
@@ -239,13 +340,15 @@ extern "C" size_t gnode_sir_workspace_bytes(gnode_graph_t g, int32_t T) {
     if (!g) return 0;
     size_t b = gn_align((size_t)2 * T * g->n * sizeof(uint32_t)) + gn_align(4096 * sizeof(int32_t)) +
                gn_align((size_t)std::max<int64_t>(g->nnz, 1) * sizeof(int32_t));
-    if ((size_t)2 * g->n > kLdsStateLimit) b += gn_align((size_t)2048 * 2 * g->n);
-    return b;
+    size_t tail = 0;                                       // one region, two users that never run together
+    if ((size_t)2 * g->n > kLdsStateLimit) tail = (size_t)2048 * 2 * g->n;                                   // scan kernel, state in memory
+    if (!frontier_lists_in_lds(g->n)) tail = std::max(tail, (size_t)kFrontierGlobalGrid * 3 * g->n * sizeof(int32_t));   // frontier lists
+    return b + gn_align(tail);
 }
 
-extern "C" int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta,
-                                   double gamma, int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed,
-                                   uint32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
+static int sir_mc_philox_impl(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta,
+                              double gamma, int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed,
+                              uint32_t* counts, void* workspace, size_t workspace_bytes, void* stream, bool edge_scan) {
     GN_CHECK_ARG(g && counts && workspace, "gnode_sir_mc_philox: null pointer");
     GN_CHECK_ARG(n_seeds >= 0 && n_seeds <= 4096 && (seeds_host || n_seeds == 0), "gnode_sir_mc_philox: 0..4096 seeds");
     GN_CHECK_ARG(T >= 1 && sims >= 0 && sims <= 0xFFFFFFFFll && sim_offset >= 0 && sim_offset + sims <= 0xFFFFFFFFll,
@@ -278,22 +381,36 @@ extern "C" int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, i
         GN_HIP(hipMemcpyAsync(seeds, seeds_host, sizeof(int32_t) * n_seeds, hipMemcpyHostToDevice, st));
         GN_HIP(hipStreamSynchronize(st));
     }
-    hipLaunchKernelGGL(k_expand_rows, dim3((g->n + 255) / 256), dim3(256), 0, st, g->rowptr, g->n, src);
-    GN_LAUNCH_CHECK();
     const unsigned long long tb = (unsigned long long)std::min(4294967296.0, std::max(0.0, std::floor(beta * 4294967296.0)));
     const unsigned long long tg = (unsigned long long)std::min(4294967296.0, std::max(0.0, std::floor(gamma * 4294967296.0)));
     const uint32_t k0 = (uint32_t)(rng_seed & 0xFFFFFFFFull), k1 = (uint32_t)(rng_seed >> 32);
     if (sims > 0) {
         const bool sampled = gn_prof_begin(3, st);
+        const size_t fl = frontier_lds_bytes(g->n);
         const size_t lds = (size_t)2 * g->n;
-        if (lds <= kLdsStateLimit) {
-            // workgroups per CU by LDS; keep >= 16 waves per CU: big states get 1024-thread workgroups
+        if (fl <= kLdsStateLimit && !edge_scan) {
+            // frontier-driven walk.  Workgroups per CU by LDS, at least 16 waves per CU
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(fl + 64, 1)));
+            const int threads = per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024);
+            if (frontier_lists_in_lds(g->n)) {
+                const int grid = (int)std::min<int64_t>(sims, (int64_t)g->num_cu * per_cu);
+                hipLaunchKernelGGL((k_sir_frontier<uint16_t, true>), dim3(grid), dim3(threads), fl, st, g->rowptr, g->col, g->n, seeds,
+                                   n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (int32_t*)nullptr);
+            } else {
+                const int grid = (int)std::min<int64_t>(std::min<int64_t>(sims, (int64_t)g->num_cu * per_cu), kFrontierGlobalGrid);
+                hipLaunchKernelGGL((k_sir_frontier<int32_t, false>), dim3(grid), dim3(threads), fl, st, g->rowptr, g->col, g->n, seeds,
+                                   n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (int32_t*)gstate);
+            }
+        } else if (lds <= kLdsStateLimit) {
+            // edge-parallel scan, node state in LDS: graphs whose frontier lists do not fit (n > ~25k with 32-bit ids)
+            hipLaunchKernelGGL(k_expand_rows, dim3((g->n + 255) / 256), dim3(256), 0, st, g->rowptr, g->n, src);
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
             const int threads = per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024);
             const int grid = (int)std::min<int64_t>(sims, (int64_t)g->num_cu * per_cu);
             hipLaunchKernelGGL(k_sir_philox<true>, dim3(grid), dim3(threads), lds, st, src, g->col, (long)g->nnz, g->n, seeds,
                                n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (uint8_t*)nullptr);
         } else {
+            hipLaunchKernelGGL(k_expand_rows, dim3((g->n + 255) / 256), dim3(256), 0, st, g->rowptr, g->n, src);
             const int grid = (int)std::min<int64_t>(sims, 2048);
             hipLaunchKernelGGL(k_sir_philox<false>, dim3(grid), dim3(256), 0, st, src, g->col, (long)g->nnz, g->n, seeds,
                                n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, gstate);
@@ -304,6 +421,20 @@ extern "C" int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, i
     hipLaunchKernelGGL(k_sir_finalize, dim3((g->n + 255) / 256), dim3(256), 0, st, hist, g->n, T, (uint32_t)sims, counts);
     GN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta,
+                                   double gamma, int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed,
+                                   uint32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
+    return sir_mc_philox_impl(g, seeds_host, n_seeds, beta, gamma, sims, sim_offset, T, rng_seed, counts, workspace,
+                              workspace_bytes, stream, false);
+}
+
+extern "C" int gnode_sir_mc_philox_scan(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta,
+                                        double gamma, int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed,
+                                        uint32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
+    return sir_mc_philox_impl(g, seeds_host, n_seeds, beta, gamma, sims, sim_offset, T, rng_seed, counts, workspace,
+                              workspace_bytes, stream, true);
 }
 
 extern "C" int gnode_sir_mc_coins(const int32_t* table_src, const int32_t* table_dst, int64_t n_table, int32_t n,

@@ -57,19 +57,21 @@ def _device_graph_for(G):
 
 
 def sir_counts(graph: DeviceGraph, seed_set, beta, gamma, sims, T, rng_seed, sim_offset=0, device="cuda",
-               counts: torch.Tensor | None = None) -> torch.Tensor:
+               counts: torch.Tensor | None = None, edge_scan: bool = False) -> torch.Tensor:
     """Production Monte-Carlo on the GPU: uint32 (stored as int32 tensor) counts [3, T, n].
 
-    `counts` may be passed to accumulate several shards of the sims range into one array."""
+    `counts` may be passed to accumulate several shards of the sims range into one array.  edge_scan=True runs the
+    edge-parallel statement of the same model (`gnode_sir_mc_philox_scan`: identical counts, O(nnz) per step)."""
     lib = _lib.load()
     seeds = np.ascontiguousarray(list(seed_set), dtype=np.int32)
     if counts is None:
         counts = torch.zeros((3, T, graph.n), dtype=torch.int32, device=device)
     ws_bytes = lib.gnode_sir_workspace_bytes(graph.handle, T)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=counts.device)
-    _lib.check(lib.gnode_sir_mc_philox(graph.handle, _lib.host_ptr(seeds), int(seeds.shape[0]), float(beta), float(gamma),
-                                       int(sims), int(sim_offset), int(T), C.c_uint64(int(rng_seed) & (2**64 - 1)),
-                                       _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    fn = lib.gnode_sir_mc_philox_scan if edge_scan else lib.gnode_sir_mc_philox
+    _lib.check(fn(graph.handle, _lib.host_ptr(seeds), int(seeds.shape[0]), float(beta), float(gamma),
+                  int(sims), int(sim_offset), int(T), C.c_uint64(int(rng_seed) & (2**64 - 1)),
+                  _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
     return counts
 
 

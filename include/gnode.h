@@ -141,10 +141,11 @@ int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_params* p, c
 /* ---- Monte-Carlo SIR labels ------------------------------------------------
  * sir_torch(G, seed_set, beta, gamma, sims, T): ode_nn.py:30-88.
  *
- * gnode_sir_mc_philox: production mode.  One workgroup per trajectory; coins are
- * counter-based Philox4x32-10 keyed by (edge|node, step, sim, kind) so that any
- * sharding of [sim_offset, sim_offset+sims) over GPUs reproduces the same
- * counts.  counts: device uint32 [3, T, n] (S, I, R), ACCUMULATED into (caller
+ * gnode_sir_mc_philox: production mode.  One workgroup per trajectory walking the
+ * out-edges of its current frontier (work per step = the frontier's out-degree, not
+ * nnz); coins are counter-based Philox4x32-10 keyed by (CSR position|node, step,
+ * sim, kind) so that neither the visiting order nor any sharding of
+ * [sim_offset, sim_offset+sims) over GPUs can change a count.  counts: device uint32 [3, T, n] (S, I, R), ACCUMULATED into (caller
  * zeroes it); rows t >= 1 add one per trajectory per node, row 0 of S and I is
  * written with the initial state once (reference quirk: assigned, ode_nn.py:55-56).
  * Up to 32 seeds travel as a kernel argument (nothing is synchronised); with more,
@@ -162,6 +163,14 @@ size_t gnode_sir_coins_workspace_bytes(void);                    /* for gnode_si
 int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta, double gamma,
                         int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed, uint32_t* counts,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The same model, same coins, same counts by the edge-parallel statement: every workgroup tests EVERY directed edge
+ * against the infected set each step (what the reference's `isin` scan does, ode_nn.py:61), O(nnz) per trajectory-step
+ * whatever the frontier.  gnode_sir_mc_philox walks the frontier's rows instead and falls back to this scan only for
+ * graphs whose frontier lists do not fit the LDS; exported as the cross-check of that kernel and as its measured
+ * baseline. */
+int gnode_sir_mc_philox_scan(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta, double gamma,
+                             int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed, uint32_t* counts,
+                             void* workspace, size_t workspace_bytes, void* stream);
 int gnode_sir_mc_coins(const int32_t* table_src, const int32_t* table_dst, int64_t n_table, int32_t n,
                        const int32_t* seeds_host, int32_t n_seeds, double beta, double gamma, int64_t sims,
                        int32_t T, const double* coins, int64_t n_coins, uint32_t* counts,

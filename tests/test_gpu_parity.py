@@ -506,6 +506,36 @@ def test_sir_large_state_paths(dev):
     assert used_gpu == used and np.array_equal(c[0][None], S) and np.array_equal(c[1][None], I) and np.array_equal(c[2][None], R)
 
 
+@pytest.mark.parametrize("kind,n,m,seeds,sims,T", [
+    ("er-small", 500, 2500, [3, 499], 200, 15),                 # lists in LDS (uint16 ids)
+    ("wiki-vote-size", 7066, 100736, [1, 3533], 96, 20),        # lists in LDS, three workgroups per CU
+    ("hubs", 3000, 40000, [0, 1, 2999], 64, 12),                # rows longer than 512 edges: walked by the whole workgroup
+    ("global-lists", 12000, 60000, [5, 6, 5, 11999], 48, 10),   # lists in the workspace (int32 ids); a duplicated seed
+    ("isolated", 300, 40, [7], 64, 6),                          # mostly isolated nodes: the frontier dies out
+])
+def test_sir_frontier_equals_edge_scan(kind, n, m, seeds, sims, T, dev):
+    """The frontier-driven Monte-Carlo kernel against the edge-parallel scan of the same model in the same library
+    (gnode_sir_mc_philox_scan: every edge tested every step, what the reference's `isin` does) and against the C
+    oracle: identical uint32 counts.  beta high enough that most of the graph burns, gamma low enough that the
+    frontier stays large for several steps."""
+    import gnode_oracle as O
+    import oracle_c as OC
+    from gnode.graph import DeviceGraph
+    from gnode.ode_nn import sir_counts
+    if kind == "hubs":
+        rp, ci, _ = O.chung_lu_graph(n, m, exponent=0.95, seed=3)
+        assert int(np.max(np.diff(rp))) > 512
+    else:
+        rp, ci, _ = O.er_graph(n, m, seed=n)
+    g = DeviceGraph(rp, ci)
+    for beta, gamma, rs in ((0.45, 0.15, 11), (0.05, 0.6, 12)):
+        a = sir_counts(g, seeds, beta, gamma, sims, T, rng_seed=rs).cpu().numpy().astype(np.uint32)
+        b = sir_counts(g, seeds, beta, gamma, sims, T, rng_seed=rs, edge_scan=True).cpu().numpy().astype(np.uint32)
+        assert np.array_equal(a, b), f"{kind}: frontier walk != edge scan (beta={beta})"
+        assert np.array_equal(a, OC.sir_philox(n, rp, ci, seeds, beta, gamma, sims, T, rng_seed=rs)), f"{kind}: != oracle"
+        assert np.all(a[0, 1:].astype(np.int64) + a[1, 1:] + a[2, 1:] == sims)
+
+
 def test_c_abi_standalone_host(tmp_path, dev):
     """The boundary is a C ABI: a C++ host with no Python/torch in the process builds against include/gnode.h,
     links libgnode_hip.so and gets the same numbers as the Python host path."""
