@@ -142,12 +142,15 @@ def bench_train(lib, dev, n, m, B, H, maxTime, deltaT, reps):
 
 
 def bwd_interval_bytes(n, nnz, H):
-    """One sample, one interval of the fused adjoint kernel: gathers + slab rows it reads and writes."""
+    """One sample, one interval of the fused adjoint kernel (k_bwd_fused64<.,.,false>): the A q
+    gather (A Z_I(y_i) is read back from the slab the forward kept) plus the slab rows it reads and writes:
+    reads a_S, a_I, a_R (3) + y_i S, I rows (2) + kept A Z_I row (1) + y_{i-1} S row (1) + y_{i-1} I, R rows at output grid
+    points (every second interval with the fused subsample: 1 on average); writes a_S, a_I (2) + a_R at output points (0.5)
+    + the next interval's q table (1)."""
     slab = n * H * 4
-    gathers = 1                      # A q only: A Z_I of the interval is read back from the forward's saved AI slab
-    slabs = 3 + 3 + 3 + 2 + 2 + 2    # a (r+w: 3+3), sol[i] S/I/R rows + AI, sol[i-1] rows for the next tables, Z_S/Z_I/q tables r+w
+    slabs = 3 + 2 + 1 + 1 + 1 + 2 + 0.5 + 1
     csr = nnz * 4 + (n + 1) * 4
-    return {"algorithmic": csr + gathers * nnz * H * 4 + slabs * slab, "compulsory": csr + slabs * slab}
+    return {"algorithmic": csr + nnz * H * 4 + slabs * slab, "compulsory": csr + slabs * slab}
 
 
 def bench_sir(lib, dev, n, m, sims, T):

@@ -388,8 +388,9 @@ static_assert(GN_BWD_RPG1_OCC * 256 <= BWD_NWG, "fused backward grid exceeds the
 template <int OCC, int RPG, bool GATHER_AI>
 __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                      long rows, int tiles_per_sample, long total_tiles,
-                                                     float* __restrict__ ZS, const float* __restrict__ ZIc,
-                                                     const float* __restrict__ Qc, float* __restrict__ ZIn,
+                                                     const float* __restrict__ ZIc, const float* __restrict__ Qc,
+                                                     float* __restrict__ ZIn /* next interval's Z_I table, or null when it
+                                                     will read the kept A Z_I instead of gathering */,
                                                      float* __restrict__ Qn, const float* __restrict__ Ysol,
                                                      const float* __restrict__ Yprev, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ beta,
@@ -428,52 +429,64 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
         const long b = t / tiles_per_sample;
         const int tile = (int)(t - b * tiles_per_sample);
         const long base = b * n;
-        bool valid[RPG]; size_t off[RPG]; float4 aS[RPG], aI[RPG], aR[RPG]; float bt[RPG];
+        bool valid[RPG]; size_t off[RPG]; float4 aS[RPG], aI[RPG], aR[RPG], ai[RPG], gq[RPG]; float bt[RPG], gmv[RPG];
         __syncthreads();                                   // previous tile fully consumed (and W staged)
 #pragma unroll
         for (int p = 0; p < RPG; ++p) {
             const int node = tile * TR + lr[p];
             valid[p] = node < n;
             off[p] = (size_t)(base + node) * 64 + 4 * sub;
-            // own-row loads first: they travel under the gather's dependent id -> row round trips
-            float4 dS = zero4(), dI = zero4(), zs = zero4(), zi = zero4(), ysr = zero4(), yir = zero4();
-            float gm = 0.f;
+            // own-row loads first: they travel under the gather's dependent id -> row round trips.  The row's own
+            // Z_S(y_i), Z_I(y_i) are RECOMPUTED from the y_i rows staged for the gW contraction anyway (one more matrix
+            // phase) instead of being written by the previous interval and read back: 4 of 17 slab transfers less
+            float4 ysr = zero4(), yir = zero4();
+            gmv[p] = 0.f;
             aS[p] = zero4(); aI[p] = zero4(); aR[p] = zero4(); bt[p] = 0.f;
             if (valid[p]) {
                 bt[p] = beta[base + node];
-                gm = gamma[base + node];
+                gmv[p] = gamma[base + node];
                 aS[p] = ld4g(a + off[p]); aI[p] = ld4g(a + slab + off[p]); aR[p] = ld4g(a + 2 * slab + off[p]);
-                zs = ld4g(ZS + off[p]); zi = ld4g(ZIc + off[p]);
                 ysr = ld4g(Ysol + off[p]); yir = ld4g(Ysol + slab + off[p]);
             }
-            float4 ai, gq;
+            *reinterpret_cast<float4*>(&Yt[0][lr[p] * TS + 4 * sub]) = ysr;
+            *reinterpret_cast<float4*>(&Yt[1][lr[p] * TS + 4 * sub]) = yir;
             const int hub = (hubidx && valid[p]) ? hubidx[node] : -1;
             if (GATHER_AI) {
                 if (hub >= 0) {
-                    ai = ld4g(AIhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
-                    gq = ld4g(GQhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+                    ai[p] = ld4g(AIhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+                    gq[p] = ld4g(GQhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
                 } else {
-                    gather2_row64<GN_BWD_NB>(rowptr, col, ZIc + (size_t)base * 64, Qc + (size_t)base * 64, node, valid[p], sub, ai, gq);
+                    gather2_row64<GN_BWD_NB>(rowptr, col, ZIc + (size_t)base * 64, Qc + (size_t)base * 64, node, valid[p], sub, ai[p], gq[p]);
                 }
             } else {
-                ai = valid[p] ? ld4g(AIsaved + off[p]) : zero4();
-                if (hub >= 0) gq = ld4g(GQhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
-                else gq = gather1_row64<>(rowptr, col, Qc + (size_t)base * 64, node, valid[p], sub);
+                ai[p] = valid[p] ? ld4g(AIsaved + off[p]) : zero4();
+                if (hub >= 0) gq[p] = ld4g(GQhub + ((size_t)b * n_hub + hub) * 64 + 4 * sub);
+                else gq[p] = gather1_row64<>(rowptr, col, Qc + (size_t)base * 64, node, valid[p], sub);
             }
+        }
+        __syncthreads();
+        // Z_S(y_i), Z_I(y_i) of the tile's rows on the matrix cores (the engine and summation order of the forward)
+        if (RPG == 2) { mfma_tile<true>(Yt[0], Wl, Dt[0], bias_l, w, lane); mfma_tile<true>(Yt[1], Wl, Dt[1], bias_l, w, lane); }
+        else { mfma_tile16<true>(Yt[0], Wl, Dt[0], bias_l, w, lane); mfma_tile16<true>(Yt[1], Wl, Dt[1], bias_l, w, lane); }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < RPG; ++p) {
+            float4 dS = zero4(), dI = zero4();
             if (valid[p]) {
+                const float4 zs = *reinterpret_cast<const float4*>(&Dt[0][lr[p] * TS + 4 * sub]);
+                const float4 zi = *reinterpret_cast<const float4*>(&Dt[1][lr[p] * TS + 4 * sub]);
+                const float gm = gmv[p];
 #define GN_DP(c)                                                               \
                 {                                                              \
                     const float v = bt[p] * (aI[p].c - aS[p].c);               \
-                    dS.c = (v * ai.c) * (zs.c * (1.0f - zs.c));                \
-                    dI.c = (gq.c + gm * (aR[p].c - aI[p].c)) * (zi.c * (1.0f - zi.c)); \
+                    dS.c = (v * ai[p].c) * (zs.c * (1.0f - zs.c));             \
+                    dI.c = (gq[p].c + gm * (aR[p].c - aI[p].c)) * (zi.c * (1.0f - zi.c)); \
                 }
                 GN_DP(x) GN_DP(y) GN_DP(z) GN_DP(w)
 #undef GN_DP
             }
-            *reinterpret_cast<float4*>(&Dt[0][lr[p] * TS + 4 * sub]) = dS;
+            *reinterpret_cast<float4*>(&Dt[0][lr[p] * TS + 4 * sub]) = dS;      // own row only: read above, rewritten here
             *reinterpret_cast<float4*>(&Dt[1][lr[p] * TS + 4 * sub]) = dI;
-            *reinterpret_cast<float4*>(&Yt[0][lr[p] * TS + 4 * sub]) = ysr;
-            *reinterpret_cast<float4*>(&Yt[1][lr[p] * TS + 4 * sub]) = yir;
         }
         __syncthreads();
 #pragma unroll
@@ -511,7 +524,8 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
                 const float4 uI = *reinterpret_cast<const float4*>(&Yt[1][lr[p] * TS + 4 * sub]);
                 aS[p].x += dt * uS.x; aS[p].y += dt * uS.y; aS[p].z += dt * uS.z; aS[p].w += dt * uS.w;
                 aI[p].x += dt * uI.x; aI[p].y += dt * uI.y; aI[p].z += dt * uI.z; aI[p].w += dt * uI.w;
-                if (head || do_next) { y[0] = ld4g(Yprev + off[p]); y[1] = ld4g(Yprev + slab + off[p]); }
+                if (head || do_next) y[0] = ld4g(Yprev + off[p]);
+                if (head || (do_next && ZIn)) y[1] = ld4g(Yprev + slab + off[p]);
                 if (head) {
                     y[2] = ld4g(Yprev + 2 * slab + off[p]);
                     const size_t o = (size_t)(base + tile * TR + lr[p]);
@@ -520,7 +534,7 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
             }
             if (do_next) {
                 *reinterpret_cast<float4*>(&Yt[0][lr[p] * TS + 4 * sub]) = y[0];
-                *reinterpret_cast<float4*>(&Yt[1][lr[p] * TS + 4 * sub]) = y[1];
+                if (ZIn) *reinterpret_cast<float4*>(&Yt[1][lr[p] * TS + 4 * sub]) = y[1];
             }
             if (head) {
                 float4 w3v[4];
@@ -532,17 +546,20 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
             if (valid[p]) { st4g(a + off[p], aS[p]); st4g(a + slab + off[p], aI[p]); }
         }
         if (do_next) {
-            // Z(y_{i-1}) and q for the next interval
+            // q = beta (a_I - a_S) * Z_S(y_{i-1}): the table the NEXT interval gathers (its own-row Z_S, Z_I are recomputed there)
             __syncthreads();
-            if (RPG == 2) { mfma_tile<true>(Yt[0], Wl, Dt[0], bias_l, w, lane); mfma_tile<true>(Yt[1], Wl, Dt[1], bias_l, w, lane); }
-            else { mfma_tile16<true>(Yt[0], Wl, Dt[0], bias_l, w, lane); mfma_tile16<true>(Yt[1], Wl, Dt[1], bias_l, w, lane); }
+            if (RPG == 2) mfma_tile<true>(Yt[0], Wl, Dt[0], bias_l, w, lane);
+            else mfma_tile16<true>(Yt[0], Wl, Dt[0], bias_l, w, lane);
+            if (ZIn) {                                                   // uniform: the next interval gathers A Z_I itself
+                if (RPG == 2) mfma_tile<true>(Yt[1], Wl, Dt[1], bias_l, w, lane);
+                else mfma_tile16<true>(Yt[1], Wl, Dt[1], bias_l, w, lane);
+            }
             __syncthreads();
 #pragma unroll
             for (int p = 0; p < RPG; ++p) {
                 if (!valid[p]) continue;
+                if (ZIn) st4g(ZIn + off[p], *reinterpret_cast<const float4*>(&Dt[1][lr[p] * TS + 4 * sub]));
                 const float4 zs = *reinterpret_cast<const float4*>(&Dt[0][lr[p] * TS + 4 * sub]);
-                const float4 zi = *reinterpret_cast<const float4*>(&Dt[1][lr[p] * TS + 4 * sub]);
-                st4g(ZS + off[p], zs); st4g(ZIn + off[p], zi);
                 st4g(Qn + off[p], make_float4(bt[p] * (aI[p].x - aS[p].x) * zs.x, bt[p] * (aI[p].y - aS[p].y) * zs.y,
                                               bt[p] * (aI[p].z - aS[p].z) * zs.z, bt[p] * (aI[p].w - aS[p].w) * zs.w));
             }
@@ -955,8 +972,8 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
             const float* gSs = s >= 0 ? gS + (size_t)s * rows : nullptr;
             auto fused_kernel = two ? k_bwd_fused64<GN_BWD_RPG1_OCC, 1, true> : k_bwd_fused64<GN_BWD_RPG1_OCC, 1, false>;
             const bool sampled = gn_prof_begin(2, st);
-            hipLaunchKernelGGL(fused_kernel, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, tps, total, ZS,
-                               ZIb[cur], Qb[cur], ZIb[cur ^ 1], Qb[cur ^ 1], sol + (size_t)i * 4 * slab,
+            hipLaunchKernelGGL(fused_kernel, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, tps, total,
+                               ZIb[cur], Qb[cur], ai_saved ? nullptr : ZIb[cur ^ 1], Qb[cur ^ 1], sol + (size_t)i * 4 * slab,
                                sol + (size_t)(i - 1) * 4 * slab, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma,
                                dt_host[i - 1], a, part, gSs, s >= 0 ? gI + (size_t)s * rows : nullptr,
                                s >= 0 ? gR + (size_t)s * rows : nullptr, p->linear3_weight, p->linear3_bias,

@@ -215,37 +215,43 @@ __global__ __launch_bounds__(256, StepOcc<PRJ>::value) void k_step64(const int* 
     // ---- per-stage state.  Uniform across the workgroup: *_ok (tile inside the queue).  Per lane group: the row.
     struct Stage { bool ok; bool valid; bool hub; unsigned row, base; int start, end; unsigned mine, mine2, hoff; };
     const unsigned zoff = (unsigned)rows * 256u;           // byte offset of the table's zero row (one past the last row)
-    auto fetch_head = [&](Stage& s) {                      // top of the chain: row id, rowptr, hub index (loads unconditional)
+    auto fetch_head = [&](Stage& s) {                      // top of the chain: row id, rowptr, hub index
         s.ok = t_it < q_hi;
         while (tile_it >= tiles_per_sample) { tile_it -= tiles_per_sample; ++b_it; }
         const int node = tile_it * 16 + lr;
         s.valid = s.ok && node < n;
         const int nodec = s.valid ? node : 0;
         s.row = s.valid ? (unsigned)b_it * (unsigned)n + (unsigned)node : 0u;
-        s.start = rowptr[nodec]; s.end = rowptr[nodec + 1];
-        s.hub = false; s.mine = 0u; s.hoff = 0u;
-        if (hubidx) {                                      // uniform: graphs without long rows skip all of this
-            const int h = hubidx[nodec];
-            s.hub = s.valid && h >= 0;
-            s.hoff = s.hub ? ((unsigned)b_it * (unsigned)n_hub + (unsigned)h) * 256u : 0u;
+        s.start = 0; s.end = 0; s.hub = false; s.mine = 0u; s.hoff = 0u;
+        if (s.ok) {                                        // uniform: past the end of the queue nothing is requested at all
+            s.start = rowptr[nodec]; s.end = rowptr[nodec + 1];      // (inside a tile the loads are unconditional: clamped row)
+            if (hubidx) {                                  // uniform: graphs without long rows skip all of this
+                const int h = hubidx[nodec];
+                s.hub = s.valid && h >= 0;
+                s.hoff = s.hub ? ((unsigned)b_it * (unsigned)n_hub + (unsigned)h) * 256u : 0u;
+            }
         }
         if (!s.valid) s.end = s.start;
         s.base = (unsigned)b_it * (unsigned)n;             // first row of the tile's sample (uniform)
         t_it += t_stride; tile_it += t_stride;
     };
     auto fetch_cols = [&](Stage& s) {                      // second link: the first 32 column ids as table byte offsets
-        const unsigned base = s.base;
-        const int d = s.hub ? 0 : s.end - s.start;
-        const int c0 = col[sub < d ? s.start + sub : 0], c1 = col[16 + sub < d ? s.start + 16 + sub : 0];
-        s.mine = sub < d ? (base + (unsigned)c0) * 256u : zoff;
-        s.mine2 = 16 + sub < d ? (base + (unsigned)c1) * 256u : zoff;
+        s.mine = zoff; s.mine2 = zoff;
+        if (s.ok) {
+            const unsigned base = s.base;
+            const int d = s.hub ? 0 : s.end - s.start;
+            const int c0 = col[sub < d ? s.start + sub : 0], c1 = col[16 + sub < d ? s.start + 16 + sub : 0];
+            s.mine = sub < d ? (base + (unsigned)c0) * 256u : zoff;
+            s.mine2 = 16 + sub < d ? (base + (unsigned)c1) * 256u : zoff;
+        }
         if (s.hub) s.end = s.start;                        // nothing to gather: the sum arrives from the hub kernels
     };
 
     Stage cur, n1, n2;
     cur.ok = false; cur.valid = false; cur.hub = false; cur.row = 0; cur.start = cur.end = 0; cur.mine = cur.mine2 = zoff; cur.hoff = 0; cur.base = 0;
     fetch_head(n1);
-    float4 ys_n1 = ld4so<NT>(YS, n1.row * 256u + lane_b);
+    float4 ys_n1 = zero4();
+    if (n1.ok) ys_n1 = ld4so<NT>(YS, n1.row * 256u + lane_b);
     fetch_cols(n1);
     float4 v0 = zero4(), v1 = zero4(), v2 = zero4(), v3 = zero4(), v4 = zero4(), v5 = zero4(), v6 = zero4(), v7 = zero4();
     float4 yi = zero4(), yr = zero4(), zi = zero4(), pr = zero4();
@@ -353,7 +359,9 @@ __global__ __launch_bounds__(256, StepOcc<PRJ>::value) void k_step64(const int* 
             *reinterpret_cast<float4*>(tA) = yi;                       // Y_I' -> operand of Z_I'(t)
         }
         if (n1.ok) *reinterpret_cast<float4*>(tB) = ys_n1;             // Y_S(t+1) -> operand of Z_S(t+1)
-        // ---- C: request tile t+1's first 8 neighbour rows and its own rows (they travel under the matrix phase)
+        // ---- C: request tile t+1's first 8 neighbour rows and its own rows (they travel under the matrix phase).
+        // Unconditional on purpose (past the queue's end they read row 0 and the zero row): guarding this block and the
+        // next load by the uniform `ok` flags cost 9 us per launch on the 75k graph x 8 (368 vs 359)
         {
             const unsigned m = n1.mine;
             v0 = gat_ld<0>(ZI, m, lane_b); v1 = gat_ld<1>(ZI, m, lane_b); v2 = gat_ld<2>(ZI, m, lane_b); v3 = gat_ld<3>(ZI, m, lane_b);
