@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, StepOcc<PRJ>::value) void k_step64(const int* 
 #undef GN_DUAL
         __syncthreads();
         // ---- F: next step's gather table row of tile t; column ids of tile t+2
-        if (cur.valid) st4o(ZI_next, cur.row * 256u + lane_b, *reinterpret_cast<const float4*>(t2i));
+        if (cur.valid) st4so<NT>(ZI_next, cur.row * 256u + lane_b, *reinterpret_cast<const float4*>(t2i));   // (the next launch gathers it; this one never reads it)
         fetch_cols(n2);
         if (!n1.ok) break;
         cur = n1; n1 = n2; ys_n1 = ys_n2;

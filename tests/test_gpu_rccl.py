@@ -31,3 +31,26 @@ def test_rccl_world1_collectives():
     assert out["backend"] == "nccl"
     assert out["max_ok"] and out["counts_ok"] and out["grads_ok"] and out["runner_ok"], out
     assert out["counts_dtype"] == "torch.int32"
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` typed as is: the parent (which never touches the GPU) starts two ranks with
+    torch.distributed.run, rank 0 prints ONE JSON line with the whole-job aggregate.  Both ranks share the box's one GPU
+    here, so the control plane is gloo (GNODE_DIST_BACKEND: RCCL refuses two ranks on one device); the launch path,
+    the barrier / MAX-of-elapsed protocol and the aggregation are what is under test."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GNODE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes", "3000",
+                        "--edges", "12000", "--samples", "2", "--chunk", "2", "--no-cpu-baseline", "--no-secondary"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["outputs_valid"]
+    assert abs(d["value"] - 2 * 2 * 3000 * 59 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
