@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void k_prologue64(const float* __restrict__ x,
                                                     float* __restrict__ PR,
                                                     float* __restrict__ S0, float* __restrict__ I0, float* __restrict__ R0,
                                                     long rows) {
-    if (blockIdx.x == 0 && threadIdx.x < 32) {            // the zero rows behind the two gather tables (k_step64p)
+    if (blockIdx.x == 0 && threadIdx.x < 32) {            // the zero rows behind the two gather tables (k_step64)
         float* z = (threadIdx.x < 16 ? ZI : ZI_alt) + (size_t)rows * 64 + 4 * (threadIdx.x & 15);
         st4g(z, zero4());
     }

@@ -128,8 +128,11 @@ __global__ __launch_bounds__(1024) void k_sir_frontier(const int* __restrict__ r
                                                       uint32_t* __restrict__ hist, int32_t* __restrict__ glists) {
     extern __shared__ uint32_t smem_w[];
     const int nwords = (n + 31) >> 5;
+    const int nw4 = (nwords + 3) & ~3;
     uint32_t* bits = smem_w;                                   // ever infected (seeds included): susceptible <=> bit clear
-    IdT* lists = LISTS_IN_LDS ? reinterpret_cast<IdT*>(smem_w + ((nwords + 3) & ~3))
+    uint32_t* spent = smem_w + nw4;                            // node whose neighbours have ALL been infected: its row can never
+                                                               // infect anybody again (infection is monotone) and is not walked any more
+    IdT* lists = LISTS_IN_LDS ? reinterpret_cast<IdT*>(smem_w + 2 * nw4)
                               : reinterpret_cast<IdT*>(glists + (size_t)blockIdx.x * 3 * n);
     IdT* cur = lists;
     IdT* nxt = lists + n;
@@ -138,10 +141,10 @@ __global__ __launch_bounds__(1024) void k_sir_frontier(const int* __restrict__ r
     uint32_t* hinf = hist;
     uint32_t* hrec = hist + (size_t)T * n;
     const int nthr = blockDim.x, tid = threadIdx.x;
-    const int sub = tid & 15, gid = tid >> 4, ngroups = nthr >> 4;
+    const int sub = tid & 15, gid = tid >> 4, ngroups = nthr >> 4, lane_in_wave = tid & 63;
     for (long s = blockIdx.x; s < sims; s += gridDim.x) {
         const uint32_t sim = (uint32_t)(sim_offset + s);
-        for (int w = tid; w < nwords; w += nthr) bits[w] = 0u;
+        for (int w = tid; w < nwords; w += nthr) { bits[w] = 0u; spent[w] = 0u; }
         if (tid < 3) cnt[tid] = 0;
         __syncthreads();
         for (int j = tid; j < n_seeds; j += nthr) {            // distinct seeds: one infection event at t = 0 each
@@ -158,10 +161,11 @@ __global__ __launch_bounds__(1024) void k_sir_frontier(const int* __restrict__ r
             if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
             __syncthreads();
             // infection attempts along the out-edges of the frontier: one 16-lane group per infected node
-            auto try_edge = [&](int e) {
+            auto try_edge = [&](int e) -> bool {               // returns whether the edge's target was still susceptible
                 const int v = col[e];
                 const uint32_t m = 1u << (v & 31);
-                if (!(bits[v >> 5] & m) &&
+                const bool sus = !(bits[v >> 5] & m);
+                if (sus &&
                     (unsigned long long)philox_word0((uint32_t)e, (uint32_t)it, sim, 0u, k0, k1) < thr_beta) {
                     if (!(atomicOr(&bits[v >> 5], m) & m)) {   // first edge to reach v this step (it was susceptible)
                         nxt[atomicAdd(&cnt[0], 1)] = (IdT)v;
@@ -169,13 +173,20 @@ __global__ __launch_bounds__(1024) void k_sir_frontier(const int* __restrict__ r
                         atomicAdd(&hinf[(size_t)it * n + v], 1u);
                     }
                 }
+                return sus;
             };
             if (n_ever < n)
             for (int idx = gid; idx < n_inf; idx += ngroups) {
                 const int u = (int)cur[idx];
+                const uint32_t um = 1u << (u & 31);
+                if (spent[u >> 5] & um) continue;              // every neighbour already infected: nothing left to do for u
                 const int lo = rowptr[u], hi = rowptr[u + 1];
                 if (hi - lo > GN_SIR_BIGROW) { if (sub == 0) big[atomicAdd(&cnt[1], 1)] = (IdT)u; continue; }
-                for (int e = lo + sub; e < hi; e += 16) try_edge(e);
+                bool any_sus = false;
+                for (int e = lo + sub; e < hi; e += 16) any_sus |= try_edge(e);
+                // (a target infected during this very walk still counted as susceptible: the row is retired one step later)
+                const unsigned long long bal = __ballot(any_sus);
+                if (sub == 0 && !((bal >> (lane_in_wave & 48)) & 0xFFFFull)) atomicOr(&spent[u >> 5], um);
             }
             // recovery coin of every node of the frontier (decided on the pre-step state: a node infected in this step is
             // not on `cur`); survivors go on the next list
@@ -321,7 +332,7 @@ __global__ void k_put_seeds(SeedArg sa, int n_seeds, int32_t* __restrict__ seeds
 }
 
 // LDS of the frontier kernel: bitmap (+ three uint16 node lists -- current, next, long rows -- when they fit)
-static size_t frontier_bitmap_bytes(int n) { return ((((size_t)n + 31) / 32 + 3) & ~(size_t)3) * 4; }
+static size_t frontier_bitmap_bytes(int n) { return 2 * ((((size_t)n + 31) / 32 + 3) & ~(size_t)3) * 4; }   // ever-infected + spent
 static bool frontier_lists_in_lds(int n) { return n <= 65536 && frontier_bitmap_bytes(n) + 6 * (size_t)n <= 48 * 1024; }
 static size_t frontier_lds_bytes(int n) { return frontier_bitmap_bytes(n) + (frontier_lists_in_lds(n) ? 6 * (size_t)n : 0); }
 static const int kFrontierGlobalGrid = 1024;       // workgroups that own a set of global lists (graphs past the LDS form)
