@@ -13,6 +13,8 @@ struct gnode_graph_s {
     int32_t device;   // the HIP device the CSR lives on (current device at gnode_graph_create)
     int32_t num_cu;   // its compute-unit count: persistent grids are sized from the handle, not from process globals
     int32_t* rowptr;  // device [n+1]
+    int32_t* rowhdr;  // device [n][20]: {start, end, 0, 0, first 16 column ids (0-padded)} -- the H = 64 step kernel gets a
+                      // row's extent AND its first 16 neighbour ids in ONE round trip instead of two dependent ones
     int32_t* col;     // device [nnz]
     // hub rows (gnode_hub.hip): rows longer than the hub threshold, cut into <= 32-edge segments
     int32_t n_hub, n_seg;

@@ -100,7 +100,7 @@ __device__ __forceinline__ void readout64(float4 yS, float4 yI, float4 yR, const
 // cycles; 377 us per launch on the 75k graph x 8).  Here every workgroup keeps three tiles in flight (358 us):
 //     tile t    gather being summed, SIR update, read-out                       (stages A, B)
 //     tile t+1  Y_S row in registers -> LDS, first 8 neighbour rows + own rows requested   (stages B, C)
-//     tile t+2  rowptr / hub index / Y_S row / column ids requested             (top, D, F)
+//     tile t+2  row header (extent + first 16 neighbour ids) / hub index / Y_S row / ids 16..31 requested   (top, D, F)
 // and the two node MLPs that used to be separate barrier-fenced phases -- Z_I'(t) from the updated Y_I rows and
 // Z_S(t+1) from the next tile's Y_S rows -- run in ONE matrix phase off one staged copy of W (each B fragment read
 // once for both), between the only two barriers of the iteration.  The neighbour rows of tile t+1 travel under that
@@ -156,8 +156,12 @@ __device__ __forceinline__ void mfma_dual16(const float* __restrict__ XA, const 
 // squeezed into the 128 of four waves per SIMD it spills INSIDE the loop -- a scratch reload is a vector-memory load,
 // waiting for it drains the whole prefetch pipeline -- so it runs 3 per CU (the launch time does not depend on 3 vs 4)
 template <bool PRJ> struct StepOcc { static constexpr int value = PRJ ? GN_STEP_OCC : (GN_STEP_OCC > 3 ? 3 : GN_STEP_OCC); };
-template <bool PRJ>
-__global__ __launch_bounds__(256, StepOcc<PRJ>::value) void k_step64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
+// LAT ("latency mode"): launches in which every workgroup gets at most ONE tile (graphs up to ~16k rows per launch: the
+// reference's fb-social / wiki-vote experiments at batch size 1..8).  Nothing overlaps there but a tile's own round trips,
+// and the register file is nearly empty (one or two workgroups per CU), so the gather keeps 16 neighbour rows in flight
+// per lane group instead of 8: one dependent round trip less per tile.  Same sums in the same order: bit-identical outputs.
+template <bool PRJ, bool LAT = false>
+__global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(const int* __restrict__ rowhdr, const int* __restrict__ col, int n,
                                                  long rows, int tiles_per_sample, long total_tiles,
                                                  float* Y, const float* __restrict__ ZI,
                                                  float* __restrict__ ZI_next, const float* __restrict__ W,
@@ -215,16 +219,21 @@ __global__ __launch_bounds__(256, StepOcc<PRJ>::value) void k_step64(const int* 
     // ---- per-stage state.  Uniform across the workgroup: *_ok (tile inside the queue).  Per lane group: the row.
     struct Stage { bool ok; bool valid; bool hub; unsigned row, base; int start, end; unsigned mine, mine2, hoff; };
     const unsigned zoff = (unsigned)rows * 256u;           // byte offset of the table's zero row (one past the last row)
-    auto fetch_head = [&](Stage& s) {                      // top of the chain: row id, rowptr, hub index
+    auto fetch_head = [&](Stage& s) {                      // top of the chain: row id, row header, hub index
         s.ok = t_it < q_hi;
         while (tile_it >= tiles_per_sample) { tile_it -= tiles_per_sample; ++b_it; }
         const int node = tile_it * 16 + lr;
         s.valid = s.ok && node < n;
         const int nodec = s.valid ? node : 0;
         s.row = s.valid ? (unsigned)b_it * (unsigned)n + (unsigned)node : 0u;
-        s.start = 0; s.end = 0; s.hub = false; s.mine = 0u; s.hoff = 0u;
+        s.start = 0; s.end = 0; s.hub = false; s.mine = zoff; s.hoff = 0u;
+        int c0 = 0;
         if (s.ok) {                                        // uniform: past the end of the queue nothing is requested at all
-            s.start = rowptr[nodec]; s.end = rowptr[nodec + 1];      // (inside a tile the loads are unconditional: clamped row)
+            // the row's header: extent and first 16 neighbour ids in one round trip (inside a tile the loads are
+            // unconditional: clamped row)
+            const int* h = rowhdr + (size_t)nodec * 20;
+            s.start = h[0]; s.end = h[1];
+            c0 = h[4 + sub];
             if (hubidx) {                                  // uniform: graphs without long rows skip all of this
                 const int h = hubidx[nodec];
                 s.hub = s.valid && h >= 0;
@@ -233,16 +242,15 @@ __global__ __launch_bounds__(256, StepOcc<PRJ>::value) void k_step64(const int* 
         }
         if (!s.valid) s.end = s.start;
         s.base = (unsigned)b_it * (unsigned)n;             // first row of the tile's sample (uniform)
+        if (sub < (s.hub ? 0 : s.end - s.start)) s.mine = (s.base + (unsigned)c0) * 256u;
         t_it += t_stride; tile_it += t_stride;
     };
-    auto fetch_cols = [&](Stage& s) {                      // second link: the first 32 column ids as table byte offsets
-        s.mine = zoff; s.mine2 = zoff;
+    auto fetch_cols = [&](Stage& s) {                      // second link: column ids 16..31 (rows longer than the header's 16)
+        s.mine2 = zoff;
         if (s.ok) {
-            const unsigned base = s.base;
             const int d = s.hub ? 0 : s.end - s.start;
-            const int c0 = col[sub < d ? s.start + sub : 0], c1 = col[16 + sub < d ? s.start + 16 + sub : 0];
-            s.mine = sub < d ? (base + (unsigned)c0) * 256u : zoff;
-            s.mine2 = 16 + sub < d ? (base + (unsigned)c1) * 256u : zoff;
+            const int c1 = col[16 + sub < d ? s.start + 16 + sub : 0];
+            s.mine2 = 16 + sub < d ? (s.base + (unsigned)c1) * 256u : zoff;
         }
         if (s.hub) s.end = s.start;                        // nothing to gather: the sum arrives from the hub kernels
     };
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(256, StepOcc<PRJ>::value) void k_step64(const int* 
     if (n1.ok) ys_n1 = ld4so<NT>(YS, n1.row * 256u + lane_b);
     fetch_cols(n1);
     float4 v0 = zero4(), v1 = zero4(), v2 = zero4(), v3 = zero4(), v4 = zero4(), v5 = zero4(), v6 = zero4(), v7 = zero4();
+    float4 v8 = zero4(), v9 = zero4(), v10 = zero4(), v11 = zero4(), v12 = zero4(), v13 = zero4(), v14 = zero4(), v15 = zero4();   // LAT only
     float4 yi = zero4(), yr = zero4(), zi = zero4(), pr = zero4();
     float nb = 0.f, gm = 0.f;
     __syncthreads();                                       // W staged
@@ -283,11 +292,28 @@ __global__ __launch_bounds__(256, StepOcc<PRJ>::value) void k_step64(const int* 
 #define GP_FB GP_ACC(v4) GP_ACC(v5) GP_ACC(v6) GP_ACC(v7) GP_ACC(v0) GP_ACC(v1) GP_ACC(v2) GP_ACC(v3)
             // one straight-line path per gather length (wave-uniform switch): only `acc` is live at the join, so the eight
             // row registers never meet in a phi and stay eight registers
-            const int nb4 = (__any(cnt > 8) ? 1 : 0) + (__any(cnt > 12) ? 1 : 0) + (__any(cnt > 16) ? 1 : 0) +
-                            (__any(cnt > 20) ? 1 : 0) + (__any(cnt > 24) ? 1 : 0) + (__any(cnt > 28) ? 1 : 0);
+            const int nb4 = LAT ? -1 : (__any(cnt > 8) ? 1 : 0) + (__any(cnt > 12) ? 1 : 0) + (__any(cnt > 16) ? 1 : 0) +
+                                       (__any(cnt > 20) ? 1 : 0) + (__any(cnt > 24) ? 1 : 0) + (__any(cnt > 28) ? 1 : 0);
             // (GP_OPQ: a per-case opaque copy of the offsets -- otherwise the 24 broadcast addresses are hoisted above the
             //  switch as common subexpressions, 24 live VGPRs and a spill whose reload drains every load in flight)
 #define GP_OPQ unsigned mm = m, mm2 = m2; asm volatile("" : "+v"(mm), "+v"(mm2));
+            if (LAT) {
+                // 16 rows were requested; rows 16..31 (through the second id chunk) in two unconditional batches of 8
+                GP_ACC(v0) GP_ACC(v1) GP_ACC(v2) GP_ACC(v3) GP_ACC(v4) GP_ACC(v5) GP_ACC(v6) GP_ACC(v7)
+                GP_ACC(v8) GP_ACC(v9) GP_ACC(v10) GP_ACC(v11) GP_ACC(v12) GP_ACC(v13) GP_ACC(v14) GP_ACC(v15)
+                if (__any(cnt > 16)) {
+                    v0 = gat_ld<0>(ZI, m2, lane_b); v1 = gat_ld<1>(ZI, m2, lane_b); v2 = gat_ld<2>(ZI, m2, lane_b); v3 = gat_ld<3>(ZI, m2, lane_b);
+                    v4 = gat_ld<4>(ZI, m2, lane_b); v5 = gat_ld<5>(ZI, m2, lane_b); v6 = gat_ld<6>(ZI, m2, lane_b); v7 = gat_ld<7>(ZI, m2, lane_b);
+                    if (__any(cnt > 24)) {
+                        v8 = gat_ld<8>(ZI, m2, lane_b); v9 = gat_ld<9>(ZI, m2, lane_b); v10 = gat_ld<10>(ZI, m2, lane_b); v11 = gat_ld<11>(ZI, m2, lane_b);
+                        v12 = gat_ld<12>(ZI, m2, lane_b); v13 = gat_ld<13>(ZI, m2, lane_b); v14 = gat_ld<14>(ZI, m2, lane_b); v15 = gat_ld<15>(ZI, m2, lane_b);
+                        GP_ACC(v0) GP_ACC(v1) GP_ACC(v2) GP_ACC(v3) GP_ACC(v4) GP_ACC(v5) GP_ACC(v6) GP_ACC(v7)
+                        GP_ACC(v8) GP_ACC(v9) GP_ACC(v10) GP_ACC(v11) GP_ACC(v12) GP_ACC(v13) GP_ACC(v14) GP_ACC(v15)
+                    } else {
+                        GP_ACC(v0) GP_ACC(v1) GP_ACC(v2) GP_ACC(v3) GP_ACC(v4) GP_ACC(v5) GP_ACC(v6) GP_ACC(v7)
+                    }
+                }
+            } else
             switch (nb4) {
                 case 0: { GP_FA } break;
                 case 1: { GP_OPQ GP_RA(8) GP_FB } break;
@@ -366,6 +392,10 @@ __global__ __launch_bounds__(256, StepOcc<PRJ>::value) void k_step64(const int* 
             const unsigned m = n1.mine;
             v0 = gat_ld<0>(ZI, m, lane_b); v1 = gat_ld<1>(ZI, m, lane_b); v2 = gat_ld<2>(ZI, m, lane_b); v3 = gat_ld<3>(ZI, m, lane_b);
             v4 = gat_ld<4>(ZI, m, lane_b); v5 = gat_ld<5>(ZI, m, lane_b); v6 = gat_ld<6>(ZI, m, lane_b); v7 = gat_ld<7>(ZI, m, lane_b);
+            if (LAT) {
+                v8 = gat_ld<8>(ZI, m, lane_b); v9 = gat_ld<9>(ZI, m, lane_b); v10 = gat_ld<10>(ZI, m, lane_b); v11 = gat_ld<11>(ZI, m, lane_b);
+                v12 = gat_ld<12>(ZI, m, lane_b); v13 = gat_ld<13>(ZI, m, lane_b); v14 = gat_ld<14>(ZI, m, lane_b); v15 = gat_ld<15>(ZI, m, lane_b);
+            }
             if (hubidx) {                                              // hub rows: the whole sum arrives pre-reduced
                 const float4 h = ld4o(AIhub, n1.hoff + lane_b);
                 if (n1.hub) v0 = h;
@@ -705,12 +735,13 @@ int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, flo
     // 75k graph x 8; shrinking the grid so that every workgroup gets the same number of tiles is slower than filling
     // every slot and accepting a +-1 tile imbalance)
     const int grid = (int)std::min<long>(total, (long)g->num_cu * (PR ? StepOcc<true>::value : StepOcc<false>::value));
-    if (PR) hipLaunchKernelGGL(k_step64<true>, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, ZI_next, W,
-                               bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, PR,
-                               out, g->hubidx, AIhub, g->n_hub);
-    else hipLaunchKernelGGL(k_step64<false>, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, rows, tps, total, Y, ZI, ZI_next, W,
-                            bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, PR,
-                            out, g->hubidx, AIhub, g->n_hub);
+    const bool lat = total <= grid;            // one tile per workgroup: the latency-mode instantiation
+#define GN_STEP(P, L) hipLaunchKernelGGL((k_step64<P, L>), dim3(grid), dim3(256), 0, st, g->rowhdr, g->col, g->n, rows, tps, total, Y, ZI, \
+                                         ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,     \
+                                         p->linearS2_bias, PR, out, g->hubidx, AIhub, g->n_hub)
+    if (PR) { if (lat) GN_STEP(true, true); else GN_STEP(true, false); }
+    else { if (lat) GN_STEP(false, true); else GN_STEP(false, false); }
+#undef GN_STEP
     GN_LAUNCH_CHECK();
     return 0;
 }

@@ -530,7 +530,7 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
     GN_HIP(hipGetDevice(&dev));
     if (int e = gn_device_setup_once(dev)) return e;
     gnode_graph_s* g = new gnode_graph_s();
-    g->n = n; g->nnz = nnz; g->max_degree = maxdeg; g->rowptr = nullptr; g->col = nullptr;
+    g->n = n; g->nnz = nnz; g->max_degree = maxdeg; g->rowptr = nullptr; g->col = nullptr; g->rowhdr = nullptr;
     g->n_hub = g->n_seg = 0; g->hubidx = g->seg_lo = g->seg_hi = g->hub_seg_ptr = nullptr;
     g->device = dev;
     g->num_cu = g_dev_cu[dev];
@@ -552,7 +552,26 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
         delete g;
         return GNODE_ERR_HIP;
     }
+    {   // row headers (see gnode_common.h)
+        std::vector<int32_t> hdr((size_t)n * 20, 0);
+        for (int32_t r = 0; r < n; ++r) {
+            const int32_t lo = rowptr_host[r], hi = rowptr_host[r + 1];
+            hdr[(size_t)r * 20] = lo; hdr[(size_t)r * 20 + 1] = hi;
+            for (int32_t k = 0; k < 16 && lo + k < hi; ++k) hdr[(size_t)r * 20 + 4 + k] = col_host[lo + k];
+        }
+        hipError_t e5 = hipMalloc(&g->rowhdr, sizeof(int32_t) * hdr.size());
+        if (e5 == hipSuccess) e5 = hipMemcpy(g->rowhdr, hdr.data(), sizeof(int32_t) * hdr.size(), hipMemcpyHostToDevice);
+        if (e5 != hipSuccess) {
+            gnode_set_error("gnode_graph_create: row headers: %s", hipGetErrorString(e5));
+            if (g->rowhdr) (void)hipFree(g->rowhdr);
+            (void)hipFree(g->rowptr);
+            (void)hipFree(g->col);
+            delete g;
+            return GNODE_ERR_HIP;
+        }
+    }
     if (int e = gn_hub_build(g, rowptr_host)) {
+        (void)hipFree(g->rowhdr);
         gn_hub_free(g);
         (void)hipFree(g->rowptr);
         (void)hipFree(g->col);
@@ -568,6 +587,7 @@ extern "C" int gnode_graph_destroy(gnode_graph_t g) {
     gn_hub_free(g);
     (void)hipFree(g->rowptr);
     (void)hipFree(g->col);
+    if (g->rowhdr) (void)hipFree(g->rowhdr);
     delete g;
     return 0;
 }
