@@ -421,10 +421,14 @@ def test_full_size_short_horizon_vs_oracle(dev):
 
 # ------------------------------------------------------------------ degree skew (hub rows)
 @pytest.mark.parametrize("n,m,B,H,method", [(1500, 20000, 3, 64, "euler"), (1500, 20000, 2, 8, "euler"),
-                                             (900, 9000, 2, 32, "rk4"), (7066, 100736, 2, 64, "euler")])
+                                             (900, 9000, 2, 32, "rk4"), (7066, 100736, 2, 64, "euler"),
+                                             (7066, 100736, 3, 64, "euler")])
 def test_skewed_degree_graph_vs_oracle(n, m, B, H, method, dev):
     """Power-law-like graphs (hubs of degree ~ n/3, far above the hub threshold) go through the segmented hub
-    path; results must still match the oracle, and a batched run must equal per-sample runs bit for bit."""
+    path; results must still match the oracle, and a batched run must equal per-sample runs bit for bit.  The last
+    case is batched past the persistent grid (1 326 tiles: the pipelined instantiation, several tiles per workgroup)
+    while its single sample runs in latency mode (one tile per workgroup, 16 rows in flight): the two instantiations
+    of the step kernel must agree bit for bit, hub rows and 33..96-edge rows included."""
     import torch
     import gnode_oracle as O
     import oracle_c as OC
