@@ -600,6 +600,224 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
     }
 }
 
+// --------------------------------------------------------------------------- the interval kernel over KEPT activations
+// k_bwd_fused64 is FP32-issue bound: on gfx950 the exact-fp32 MFMA and the VALU share the fp32 lanes, and it spends them on
+// seven 64x64 products and 192 sigmoids per row.  Three of the products and every sigmoid only RECOMPUTE what the training
+// forward had in registers: Z_S(y_i), Z_I(y_i) (for sigma') and Z_S(y_{i-1}) (for the next interval's q table).  When the
+// forward kept them (gnode_forward_f32's `keep`, gn_keep_zs / gn_keep_zi) this kernel reads them back -- 2.5 slabs more
+// traffic per interval for 43 % fewer matrix instructions and no transcendental at all -- and what is left needs two
+// barriers per tile instead of seven: rows in, dpre -> LDS | gW += dpre^T y and g_Y = dpre W | rows out.
+#ifndef GN_BWD_KEPT_HEAD_OCC
+#define GN_BWD_KEPT_HEAD_OCC 2
+#endif
+template <int OCC, bool HEAD>
+__global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__ rowhdr, const int* __restrict__ col, int n, long rows,
+                                                    int tiles_per_sample, long total_tiles, const float* __restrict__ Qc,
+                                                    float* __restrict__ Qn, const float* __restrict__ Ysol,
+                                                    const float* __restrict__ Yprev, const float* __restrict__ ZSk,
+                                                    const float* __restrict__ ZIk, const float* __restrict__ ZSp,
+                                                    const float* __restrict__ AIk, const float* __restrict__ W,
+                                                    const float* __restrict__ beta, const float* __restrict__ gamma, float dt,
+                                                    float* __restrict__ a, float* __restrict__ part_all,
+                                                    const float* __restrict__ gS, const float* __restrict__ gI,
+                                                    const float* __restrict__ gR, const float* __restrict__ w3,
+                                                    const float* __restrict__ b3, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, const int* __restrict__ hubidx,
+                                                    const float* __restrict__ GQhub, int n_hub, int do_next) {
+    __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
+    __shared__ __attribute__((aligned(16))) float tiles[6][16 * TS];
+    float (*Dt)[16 * TS] = &tiles[0];              // Dt[0..1]: dpre_S, dpre_I
+    float (*Yt)[16 * TS] = &tiles[2];              // Yt[0..1]: y_S, y_I rows of grid point i
+    float (*Gt)[16 * TS] = &tiles[4];              // Gt[0..1]: g_Y = dpre W
+    const PartLayout L{64};
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
+    const int i = lane & 15, kq = lane >> 4;
+    load_W_to_lds<false>(W, Wl);
+    const size_t slab = (size_t)rows * 64;
+    const float* aSp = a; const float* aIp = a + slab; const float* aRp = a + 2 * slab;
+    const float* YIs = Ysol + slab;
+    const float* YpI = Yprev + slab; const float* YpR = Yprev + 2 * slab;
+    const int lr = w * 4 + g, ro = lr * TS + 4 * sub;
+    const unsigned lane_b = 16u * sub;
+    constexpr bool head = HEAD;                    // compile-time: the accumulators of the head's parameter gradients exist only here
+    HeadAcc hacc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hacc.dw3[k] = zero4(); hacc.db3[k] = 0.f; hacc.dw2[k] = 0.f; }
+    hacc.db2 = 0.f;
+    f32x4 accW[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) accW[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 accb = zero4();                         // this lane group's share of gb (4 features of its rows)
+    // XCD-affine tile queues, as k_bwd_fused64; everything about a row is 32-bit (the launcher bounds rows < 2^24)
+    const int xq = (gridDim.x % 8 == 0 && total_tiles >= 32) ? 8 : 1;
+    const int q_lo = (int)(total_tiles * (blockIdx.x % xq) / xq), q_hi = (int)(total_tiles * (blockIdx.x % xq + 1) / xq);
+    const int t_stride = gridDim.x / xq;
+    // The tile loop is software-pipelined one tile deep for everything that has a dependent round trip or feeds the
+    // matrix phase: a row's header (extent + first 16 neighbour ids, one load) is fetched a tile ahead; its first 8
+    // neighbour rows of the q table and its y_S, y_I rows are requested right before the PREVIOUS tile's matrix phase
+    // and land under it; the rows only the epilogue needs (Z_S(y_{i-1}), y_{i-1}, the output cotangents) are requested
+    // there too.  What is left at the top of a tile is one round trip: a, the kept Z_S, Z_I, A Z_I and neighbours 8..15.
+    // Loads inside a tile are UNCONDITIONAL (no per-row branches: the register allocator loses the rolling gather
+    // registers across them): padding rows read row 0 and are masked where it matters, absent neighbours read the q
+    // table's ZERO ROW (row `rows`, kept zero by the host).
+    struct Row { bool valid, hub; int start, end, cnt; unsigned row, rowbase, mine, hoff; };
+    const unsigned zoff = (unsigned)rows * 256u;
+    auto head_of = [&](int t, Row& r) {
+        const int bq = t / tiles_per_sample;
+        const int node = (t - bq * tiles_per_sample) * 16 + lr;
+        r.valid = t < q_hi && node < n;
+        const int nodec = r.valid ? node : 0;
+        r.rowbase = r.valid ? (unsigned)bq * (unsigned)n : 0u;      // first row of the tile's sample
+        r.row = r.rowbase + (unsigned)nodec;
+        const int* h = rowhdr + (size_t)nodec * 20;
+        r.start = h[0]; r.end = r.valid ? h[1] : r.start;
+        const int c0 = h[4 + sub];
+        r.hub = false; r.hoff = 0u;
+        if (hubidx) {                                               // uniform
+            const int hb = hubidx[nodec];
+            r.hub = r.valid && hb >= 0;
+            r.hoff = r.hub ? (unsigned)(bq * n_hub + hb) * 256u : 0u;
+        }
+        r.cnt = r.hub ? 0 : r.end - r.start;
+        r.mine = (sub < r.cnt) ? (r.rowbase + (unsigned)c0) * 256u : zoff;
+    };
+    float4 v0, v1, v2, v3, v4, v5, v6, v7;
+#define GN_PF(K, V) V = ld4o(Qc, (unsigned)row_bcast<(K) & 15>((int)m_) + lane_b);
+#define GN_ISSUE8(M, K0) { const unsigned m_ = M; GN_PF(K0, v0) GN_PF(K0 + 1, v1) GN_PF(K0 + 2, v2) GN_PF(K0 + 3, v3) \
+                                                  GN_PF(K0 + 4, v4) GN_PF(K0 + 5, v5) GN_PF(K0 + 6, v6) GN_PF(K0 + 7, v7) }
+#define GN_AC1(U) gq.x += U.x; gq.y += U.y; gq.z += U.z; gq.w += U.w;
+#define GN_ACC8 GN_AC1(v0) GN_AC1(v1) GN_AC1(v2) GN_AC1(v3) GN_AC1(v4) GN_AC1(v5) GN_AC1(v6) GN_AC1(v7)
+    Row cur, nxt;
+    int t = q_lo + blockIdx.x / xq;
+    head_of(t, cur);
+    {
+        const float4 ys = ld4o(Ysol, cur.row * 256u + lane_b), yi = ld4o(YIs, cur.row * 256u + lane_b);
+        GN_ISSUE8(cur.mine, 0)
+        *reinterpret_cast<float4*>(&Yt[0][ro]) = ys; *reinterpret_cast<float4*>(&Yt[1][ro]) = yi;
+    }
+    for (; t < q_hi; t += t_stride) {
+        head_of(t + t_stride, nxt);                    // next tile's header: requested before this tile's own rows
+        const bool valid = cur.valid;
+        const unsigned off = cur.row * 256u + lane_b;
+        const float bt = valid ? beta[cur.row] : 0.f, gm = gamma[cur.row];
+        float4 aS = ld4o(aSp, off), aI = ld4o(aIp, off), aR = ld4o(aRp, off);
+        const float4 zs = ld4o(ZSk, off), zi = ld4o(ZIk, off), ai = ld4o(AIk, off);
+        float4 gq = zero4();
+        if (hubidx) {                                  // uniform: hub rows arrive pre-summed (their gather reads zero rows)
+            const float4 hq = ld4o(GQhub, cur.hoff + lane_b);
+            if (cur.hub) gq = hq;
+        }
+        // finish the gather: neighbours 0..7 are in flight since the previous tile; ascending column order throughout
+        GN_ACC8
+        if (__any(cur.cnt > 8)) { GN_ISSUE8(cur.mine, 8) GN_ACC8 }
+        if (__any(cur.cnt > 16)) {
+            for (int e0 = cur.start + 16; __any(e0 < cur.end && !cur.hub); e0 += 16) {
+                const int c2 = cur.hub ? 0 : cur.end - e0;
+                const unsigned m2 = (sub < c2) ? (cur.rowbase + (unsigned)col[e0 + sub]) * 256u : zoff;
+                GN_ISSUE8(m2, 0) GN_ACC8
+                if (__any(c2 > 8)) { GN_ISSUE8(m2, 8) GN_ACC8 }
+            }
+        }
+        {
+            float4 dS, dI;
+#define GN_DP(c)                                                               \
+            {                                                                  \
+                const float v = bt * (aI.c - aS.c);                            \
+                dS.c = (v * ai.c) * (zs.c * (1.0f - zs.c));                    \
+                dI.c = valid ? (gq.c + gm * (aR.c - aI.c)) * (zi.c * (1.0f - zi.c)) : 0.f;   \
+            }
+            GN_DP(x) GN_DP(y) GN_DP(z) GN_DP(w)
+#undef GN_DP
+            accb.x += dS.x + dI.x; accb.y += dS.y + dI.y; accb.z += dS.z + dI.z; accb.w += dS.w + dI.w;
+            *reinterpret_cast<float4*>(&Dt[0][ro]) = dS; *reinterpret_cast<float4*>(&Dt[1][ro]) = dI;
+        }
+        __syncthreads();
+        // requests that travel under the matrix phase: this tile's epilogue rows, then the next tile's y rows and first
+        // 8 neighbour rows
+        float4 zsp = zero4();
+        float4 y[3] = {zero4(), zero4(), zero4()};
+        float gout[3] = {0.f, 0.f, 0.f};
+        if (do_next) zsp = ld4o(ZSp, off);
+        if (head) {
+            y[0] = ld4o(Yprev, off); y[1] = ld4o(YpI, off); y[2] = ld4o(YpR, off);
+            gout[0] = valid ? gS[cur.row] : 0.f; gout[1] = valid ? gI[cur.row] : 0.f; gout[2] = valid ? gR[cur.row] : 0.f;
+        }
+        const float4 ysn = ld4o(Ysol, nxt.row * 256u + lane_b), yin = ld4o(YIs, nxt.row * 256u + lane_b);
+        GN_ISSUE8(nxt.mine, 0)
+        // gW += dpre^T y (contraction over the tile's 16 rows), then g_Y = dpre W: one matrix phase
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+#pragma unroll
+            for (int s8 = 0; s8 < 4; ++s8) {
+                const int rr = 4 * s8 + kq;
+                const float av = Dt[X][rr * TS + 16 * w + i];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    accW[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Yt[X][rr * TS + 16 * kt + i], accW[kt], 0, 0, 0);
+            }
+        }
+        mfma_tile16<false, true>(Dt[0], Wl, Gt[0], 0.f, w, lane);
+        mfma_tile16<false, true>(Dt[1], Wl, Gt[1], 0.f, w, lane);
+        __syncthreads();
+        // a += dt g_Y; the head's VJP at grid point i-1; the next interval's q row; stage the next tile's y rows.  (No
+        // barrier before the next tile's Dt writes: Dt / Yt were last read before the barrier above, Gt is rewritten only
+        // after the next one.)
+        {
+            const float4 uS = *reinterpret_cast<const float4*>(&Gt[0][ro]);
+            const float4 uI = *reinterpret_cast<const float4*>(&Gt[1][ro]);
+            aS.x += dt * uS.x; aS.y += dt * uS.y; aS.z += dt * uS.z; aS.w += dt * uS.w;
+            aI.x += dt * uI.x; aI.y += dt * uI.y; aI.z += dt * uI.z; aI.w += dt * uI.w;
+        }
+        if (head) {
+            float4 w3v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w3v[k] = ld4g(w3 + k * 64 + 4 * sub);      // L1-resident
+            head_vjp64(y, gout, w3v, b3, w2, b2, aS, aI, aR, hacc);                 // padding rows: gout = 0 adds nothing
+            if (valid) st4o(a + 2 * slab, off, aR);
+        }
+        if (valid) {
+            st4o(a, off, aS); st4o(a + slab, off, aI);
+            if (do_next)
+                st4o(Qn, off, make_float4(bt * (aI.x - aS.x) * zsp.x, bt * (aI.y - aS.y) * zsp.y,
+                                          bt * (aI.z - aS.z) * zsp.z, bt * (aI.w - aS.w) * zsp.w));
+        }
+        *reinterpret_cast<float4*>(&Yt[0][ro]) = ysn; *reinterpret_cast<float4*>(&Yt[1][ro]) = yin;
+        cur = nxt;
+    }
+#undef GN_ACC8
+#undef GN_AC1
+#undef GN_ISSUE8
+#undef GN_PF
+    float* part = part_all + (size_t)blockIdx.x * L.total();
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            part[L.oW() + (16 * w + 4 * kq + reg) * 64 + 16 * kt + i] += dt * accW[kt][reg];
+    // lane-group partials (gb, and the head's parameter gradients) -> this workgroup's slot, fixed order
+    __syncthreads();
+    constexpr int NE = 5 * 64 + 12;                   // 4*64 + 9 head values, then the 64 gb values; rows kept 16-B aligned
+    float* red = &tiles[0][0];                        // 16 groups x 332 floats = 21 248 B <= the six 16-row tiles (26 112 B)
+    float* mine = red + (size_t)(threadIdx.x >> 4) * NE;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(mine + k * 64 + 4 * sub) = hacc.dw3[k];
+    if (sub == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { mine[256 + k] = hacc.db3[k]; mine[260 + k] = hacc.dw2[k]; }
+        mine[264] = hacc.db2;
+    }
+    *reinterpret_cast<float4*>(mine + 268 + 4 * sub) = accb;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 268 + 64; e += 256) {
+        if (e >= 265 && e < 268) continue;
+        if (e < 265 && !head) continue;
+        float s = 0.f;
+        for (int gi = 0; gi < 16; ++gi) s += red[(size_t)gi * NE + e];
+        if (e < 265) part[L.ow3() + e] += s;
+        else part[L.ob() + (e - 268)] += dt * s;
+    }
+}
+
 // --------------------------------------------------------------------------- ONE launch per backward interval, H <= 32
 // The generic-H twin of k_bwd_fused64 for the small hidden sizes the multi-graph launcher uses (H = 8,
 // monitorer-ngraphs.py:20): a lane group of LPR = H/4 lanes owns a row; both mat-vecs (g_Y = dpre W, Z = sigmoid(W y + b))
@@ -865,9 +1083,13 @@ __global__ void k_extract_bg(const float* __restrict__ bgslab, long rows, int H,
     gamma[r] = bgslab[(size_t)r * H + 1];
 }
 
+// one workspace slab: rows x H floats plus ONE MORE ROW (the q tables' zero row, which k_bwd_kept64's gather reads for absent
+// neighbours), rounded up
+static size_t bwd_slab_bytes(int64_t rows, int32_t H) { return gn_align(((size_t)rows + 1) * H * sizeof(float)); }
+
 static size_t backward_fixed_bytes(int64_t rows, int32_t H) {
     const PartLayout L{H};
-    const size_t slab = gn_align((size_t)rows * H * sizeof(float));
+    const size_t slab = bwd_slab_bytes(rows, H);
     // a[3], Z[2], q[1], dpre[2] slabs + beta, gamma + partial buffer + reduced gradient vector
     return 8 * slab + 2 * gn_align((size_t)rows * sizeof(float)) +
            gn_align((size_t)BWD_NWG * L.total() * sizeof(float)) + gn_align((size_t)L.total() * sizeof(float));
@@ -886,8 +1108,9 @@ int gn_bwd_set_attributes() {
 
 extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
                                   int32_t n_steps, const int32_t* out_rows_host, int32_t n_out, const float* sol,
-                                  const float* gS, const float* gI, const float* gR, const gnode_params* grads,
-                                  int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream) {
+                                  const float* keep, size_t keep_bytes, const float* gS, const float* gI, const float* gR,
+                                  const gnode_params* grads, int64_t rows, int32_t H, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
     GN_CHECK_ARG(g && x && p && sol && gS && gI && gR && grads && workspace, "gnode_backward_f32: null pointer");
     GN_CHECK_ARG(n_steps >= 0 && (n_steps == 0 || dt_host), "gnode_backward_f32: bad n_steps/dt");
     GN_CHECK_ARG(H >= 4 && H <= 128 && H % 4 == 0, "gnode_backward_f32: need 4 <= H <= 128, H %% 4 == 0 (got %d)", H);
@@ -907,7 +1130,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                          "gnode_backward_f32: out_rows must be ascending grid indices in [0,%d)", G);
     hipStream_t st = (hipStream_t)stream;
     const PartLayout L{H};
-    const size_t slab = (size_t)rows * H, slab_b = gn_align(slab * sizeof(float));
+    const size_t slab = (size_t)rows * H, slab_b = bwd_slab_bytes(rows, H);
     const size_t vec_b = gn_align((size_t)rows * sizeof(float));
     char* ws = (char*)workspace;
     float* a = (float*)ws;                               // 3 slabs (element-contiguous inside 3 aligned slabs)
@@ -954,8 +1177,9 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     const size_t mlp_lds = ((size_t)H * H + (size_t)4 * rpw * H) * sizeof(float);
     if (H == 64 && n_steps >= 1) {
         // one launch per interval: a[3] | Z_S | Z_I(0) | q(0) | Z_I(1) | q(1)  (Z_S is row-local, the gather tables ping-pong)
-        float* ZS = Z; float* ZIb[2] = {Z + slab_b / sizeof(float), dpre};
+        float* ZS = Z; float* ZIb[2] = {Z + slab, dpre};     // (k_mlp64_q fills Z_S | Z_I element-contiguously)
         float* Qb[2] = {q, dpre + slab_b / sizeof(float)};
+        for (int k = 0; k < 2; ++k) GN_HIP(hipMemsetAsync(Qb[k] + slab, 0, (size_t)H * sizeof(float), st));   // the q tables' zero rows
         const long mt = (2 * rows + TILE_ROWS - 1) / TILE_ROWS;
         hipLaunchKernelGGL(k_mlp64_q, dim3((unsigned)std::min<long>(mt, 1024)), dim3(256), 0, st, sol + (size_t)(G - 1) * 4 * slab,
                            p->odefunc_linear_weight, p->odefunc_linear_bias, Z, a, beta, q, (long)rows);
@@ -964,6 +1188,13 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         // per interval, the unfused three-launch form 563; 16-row tiles 451)
         // does this trajectory carry A Z_I(y_i) in its 4th slabs (gnode_forward_f32 wrote it: H = 64, not the one-launch path)?
         const bool ai_saved = gn_sol_carries_ai(g, H, n_steps, out_rows_host ? n_out : G);
+        // ... and did the forward keep Z_S(y_k), Z_I(y_k) as well?  Then the intervals below the last read them back
+        const size_t keep_need = gnode_forward_keep_bytes(g, rows, H, n_steps, out_rows_host ? n_out : G);
+        if (!(ai_saved && keep_need > 0)) keep = nullptr;
+        if (keep && keep_bytes < keep_need) {
+            gnode_set_error("gnode_backward_f32: keep buffer %zu < %zu", keep_bytes, keep_need);
+            return GNODE_ERR_WORKSPACE;
+        }
         const int tps = (g->n + 15) / 16;
         const long total = (long)(rows / g->n) * tps;
         const int grid = (int)std::min<long>(std::min<long>((long)GN_BWD_RPG1_OCC * g->num_cu, BWD_NWG), total);
@@ -976,8 +1207,21 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
             else if (int e = gn_hub_gather(g, rows / g->n, 64, Qb[cur], nullptr, hub_scratch, &GQhub, nullptr, st)) return e;
             const int s = slot_of(i - 1);
             const float* gSs = s >= 0 ? gS + (size_t)s * rows : nullptr;
-            auto fused_kernel = two ? k_bwd_fused64<GN_BWD_RPG1_OCC, 1, true> : k_bwd_fused64<GN_BWD_RPG1_OCC, 1, false>;
             const bool sampled = gn_prof_begin(2, st);
+            if (keep && !two && rows < (1L << 24)) {
+                // the head instance carries 25 more accumulators and the head's temporaries: two workgroups per CU there
+                constexpr int HOCC = GN_BWD_KEPT_HEAD_OCC;
+                auto kept_kernel = gSs ? k_bwd_kept64<HOCC, true> : k_bwd_kept64<GN_BWD_RPG1_OCC, false>;
+                const int kgrid = gSs ? (int)std::min<long>((long)HOCC * g->num_cu, grid) : grid;
+                hipLaunchKernelGGL(kept_kernel, dim3(kgrid), dim3(256), 0, st, g->rowhdr, g->col, g->n, (long)rows,
+                                   tps, total, Qb[cur], Qb[cur ^ 1], sol + (size_t)i * 4 * slab, sol + (size_t)(i - 1) * 4 * slab,
+                                   gn_keep_zs(keep, rows, i), gn_keep_zi(keep, rows, i), gn_keep_zs(keep, rows, i - 1),
+                                   sol + (size_t)i * 4 * slab + 3 * slab, p->odefunc_linear_weight, beta, gamma, dt_host[i - 1],
+                                   a, part, gSs, s >= 0 ? gI + (size_t)s * rows : nullptr,
+                                   s >= 0 ? gR + (size_t)s * rows : nullptr, p->linear3_weight, p->linear3_bias,
+                                   p->linearS2_weight, p->linearS2_bias, g->hubidx, GQhub, g->n_hub, i > 1 ? 1 : 0);
+            } else {
+            auto fused_kernel = two ? k_bwd_fused64<GN_BWD_RPG1_OCC, 1, true> : k_bwd_fused64<GN_BWD_RPG1_OCC, 1, false>;
             hipLaunchKernelGGL(fused_kernel, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, tps, total,
                                ZIb[cur], Qb[cur], ai_saved ? nullptr : ZIb[cur ^ 1], Qb[cur ^ 1], sol + (size_t)i * 4 * slab,
                                sol + (size_t)(i - 1) * 4 * slab, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma,
@@ -985,6 +1229,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                                s >= 0 ? gR + (size_t)s * rows : nullptr, p->linear3_weight, p->linear3_bias,
                                p->linearS2_weight, p->linearS2_bias, g->hubidx, AIhub, GQhub, g->n_hub, i > 1 ? 1 : 0,
                                sol + (size_t)i * 4 * slab + 3 * slab);
+            }
             if (sampled) gn_prof_end(2, st);
             GN_LAUNCH_CHECK();
         }

@@ -6,6 +6,7 @@ struct Step64Out {
     float* S; float* I; float* R;   // this step's output rows [rows], or null
     float* sol;                     // sol[g+1] base ([4*rows, 64]), or null
     float* ai;                      // [rows, 64] receives this step's neighbour sums A Z_I(y_g) (kept for the backward), or null
+    float* zs;                      // [rows, 64] receives Z_S(y_g) (kept for the backward, see gn_keep_zs), or null
 };
 
 // True when gnode_forward_f32 (H = 64, trajectory kept) stores A Z_I(y_k) in the 4th slab of sol[k], 1 <= k <= n_steps - 1,

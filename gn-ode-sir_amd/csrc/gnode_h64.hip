@@ -187,6 +187,8 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
     //  reading it back -- 6 % fewer bytes through the L1-miss path, 44.5 KB of LDS, three workgroups per CU: 367 us
     //  against 360 us per launch on the 75k graph x 8.)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, sub = lane & 15;
+    // training: ZI_next may be a fresh table of the kept-activation buffer (gn_keep_zi) -- give it its zero row
+    if (!PRJ && blockIdx.x == 0 && threadIdx.x < 16) st4g(ZI_next + (size_t)rows * 64 + 4 * threadIdx.x, zero4());
     load_W_to_lds<false>(W, L + O_W);
     L[O_W3 + threadIdx.x] = w3[threadIdx.x];
     float bias_l = bias[16 * w + (lane & 15)];
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
                 st4so<NT>(YSo, off, ys); st4so<NT>(YIo, off, yi);
                 if (!PRJ) st4so<NT>(YRo, off, yr);
                 if (!PRJ && out.ai) st4so<NT>(out.ai, off, acc);
+                if (!PRJ && out.zs) st4so<NT>(out.zs, off, zs);
             }
             if (out.S) {
                 float pS, pI, pR;

@@ -26,7 +26,7 @@ void gnode_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gnode_last_error(void) { return g_err; }
-extern "C" int gnode_version(void) { return 200; }   // 200: workspace sizes take the graph handle (hub scratch is carved from the caller's workspace)
+extern "C" int gnode_version(void) { return 210; }   // 200: workspace sizes take the graph handle (hub scratch is carved from the caller's workspace); 210: forward / backward take the optional kept-activation buffer
 
 // --------------------------------------------------------------------------- instrumentation
 // HIP-event pairs around every launch of the two step kernels while enabled
@@ -39,7 +39,7 @@ static bool g_prof_on = false;
 static const int kProfKinds = 4;   // 0 = step (gather/update) kernel, 1 = node-MLP kernel, 2 = backward interval kernel, 3 = Monte-Carlo kernel
 static ProfKind g_prof[kProfKinds];
 
-static const int kProfEvery = 8;   // bracket one launch in 8: the events themselves cost GPU time
+static const int kProfEvery = 7;   // bracket one launch in 7 (odd: output and non-output intervals alternate): the events themselves cost GPU time
 static long g_prof_seq[kProfKinds] = {0, 0, 0, 0};
 static bool prof_begin(int kind, hipStream_t st);
 static void prof_mark(int kind, hipStream_t st) {
@@ -647,8 +647,8 @@ extern "C" size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, i
 
 extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
                                  int32_t n_steps, int32_t method, const int32_t* out_rows_host, int32_t n_out, float* S,
-                                 float* I, float* R, float* sol, int64_t rows, int32_t H, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 float* I, float* R, float* sol, float* keep, size_t keep_bytes, int64_t rows, int32_t H,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
     GN_CHECK_ARG(g && x && p && S && I && R && workspace, "gnode_forward_f32: null pointer");
     GN_CHECK_ARG(n_steps >= 0 && (n_steps == 0 || dt_host), "gnode_forward_f32: bad n_steps/dt");
     GN_CHECK_ARG(method == 0 || method == 1, "gnode_forward_f32: method must be 0 (euler) or 1 (rk4)");
@@ -670,6 +670,13 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         for (int i = 0; i < n_out; ++i)
             GN_CHECK_ARG(out_rows_host[i] >= 0 && out_rows_host[i] < G && (i == 0 || out_rows_host[i] > out_rows_host[i - 1]),
                          "gnode_forward_f32: out_rows must be ascending grid indices in [0,%d)", G);
+    }
+    // kept activations: only the fused H = 64 training path fills them (elsewhere the backward recomputes)
+    if (!(keep && sol && method == 0 && gnode_forward_keep_bytes(g, rows, H, n_steps, out_rows_host ? n_out : G) > 0)) keep = nullptr;
+    if (keep && keep_bytes < gnode_forward_keep_bytes(g, rows, H, n_steps, out_rows_host ? n_out : G)) {
+        gnode_set_error("gnode_forward_f32: keep buffer %zu < %zu", keep_bytes,
+                        gnode_forward_keep_bytes(g, rows, H, n_steps, out_rows_host ? n_out : G));
+        return GNODE_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t slab = (size_t)rows * H, slab_b = gn_align(slab * sizeof(float));
@@ -697,6 +704,7 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
     const bool h64 = (H == 64 && method == 0);
     float* zi_cur = Z;
     float* zi_nxt = Z + slab + (h64 ? 64 : 0);           // H = 64: each table is followed by its zero row
+    if (keep) { zi_cur = gn_keep_zi(keep, rows, 0); zi_nxt = gn_keep_zi(keep, rows, 1); }   // step k gathers table k, fills k+1
     // inference (no trajectory requested): R only feeds the read-out -> carry its 4-float projection
     float* PR = (h64 && !sol) ? prbuf : nullptr;
     if (h64 && n_steps > 0) {
@@ -741,13 +749,15 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
             // receives A Z_I(y_k), which the adjoint backward would otherwise gather again
             Step64Out out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
                              slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next,
-                             (sol && k >= 1) ? sol + (size_t)k * 4 * slab + 3 * slab : nullptr};
+                             (sol && k >= 1) ? sol + (size_t)k * 4 * slab + 3 * slab : nullptr,
+                             keep ? gn_keep_zs(keep, rows, k) : nullptr};
             const bool sampled = prof_begin(0, st);
             if (int e = gn_launch_step64(g, rows, Ycur, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,
                                          gamma, dt, p, PR, out, hub_scratch, st))
                 return e;
             if (sampled) prof_mark(0, st);
-            std::swap(zi_cur, zi_nxt);
+            if (keep) { zi_cur = zi_nxt; zi_nxt = gn_keep_zi(keep, rows, std::min(k + 2, n_steps)); }
+            else std::swap(zi_cur, zi_nxt);
         } else if (method == 0 && H < 128) {
             // generic H: one fused launch per step (gather + both node MLPs as lane-group mat-vecs); H = 128 takes the
             // two-launch branch below, whose node MLP runs on the matrix cores (a VALU mat-vec is 12x off the bound there)
@@ -805,6 +815,11 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         GN_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" size_t gnode_forward_keep_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t n_steps, int32_t n_out) {
+    if (!g || rows <= 0 || !gn_sol_carries_ai(g, H, n_steps, n_out)) return 0;
+    return gn_keep_floats((long)rows, n_steps) * sizeof(float);
 }
 
 bool gn_sol_carries_ai(const gnode_graph_s* g, int H, int n_steps, int n_out) {

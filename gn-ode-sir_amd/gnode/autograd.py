@@ -22,6 +22,7 @@ class _GNODEForward(torch.autograd.Function):
         params = dict(zip(keys, tensors))
         S, I, R, sol = ops.forward(graph, x2d, params, dts, method, out_rows, want_sol=True)
         ctx.graph, ctx.dts, ctx.method, ctx.out_rows, ctx.keys = graph, dts, method, out_rows, keys
+        ctx.keep = sol.gnode_keep            # kept activations (a plain buffer nothing else references), or None
         ctx.save_for_backward(x2d, sol, *tensors)
         return S, I, R
 
@@ -32,7 +33,8 @@ class _GNODEForward(torch.autograd.Function):
         ref = next(g for g in (gS, gI, gR) if g is not None)          # an output the loss did not use has no gradient
         gS, gI, gR = (torch.zeros_like(ref) if g is None else g for g in (gS, gI, gR))
         grads = ops.backward(ctx.graph, x2d, params, ctx.dts, ctx.method, ctx.out_rows, sol,
-                             gS.contiguous(), gI.contiguous(), gR.contiguous())
+                             gS.contiguous(), gI.contiguous(), gR.contiguous(), keep=ctx.keep)
+        ctx.keep = None
         return (None, None, None, None, None, None, *[grads[k] for k in ctx.keys])
 
 

@@ -68,8 +68,12 @@ def rhs(graph: DeviceGraph, x: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -
 
 
 def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray, method: str = "euler",
-            out_rows: np.ndarray | None = None, want_sol: bool = False, workspace: torch.Tensor | None = None):
-    """ODEBlock.forward on x2d [rows, 3+H]; returns (S, I, R) each [n_out, rows] and sol or None."""
+            out_rows: np.ndarray | None = None, want_sol: bool = False, workspace: torch.Tensor | None = None,
+            want_keep: bool = True):
+    """ODEBlock.forward on x2d [rows, 3+H]; returns (S, I, R) each [n_out, rows] and sol or None.
+
+    With want_sol (training) and want_keep, the kept activations the adjoint backward reads back (include/gnode.h: `keep`)
+    ride along as ``sol.gnode_keep`` (None on paths that keep nothing); `backward` picks them up from there."""
     lib = _lib.load()
     x2d = _f32c(x2d)
     graph.check_device(x2d)
@@ -88,18 +92,27 @@ def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray
     need = lib.gnode_forward_workspace_bytes(graph.handle, rows, H, m)
     ws = workspace if (workspace is not None and workspace.numel() >= need) else _workspace(need, dev)
     p = pack_params(params)
+    keep = None
+    if sol is not None and want_keep and m == 0:
+        kb = lib.gnode_forward_keep_bytes(graph.handle, rows, H, n_steps, n_out)
+        if kb:
+            keep = torch.empty(kb // 4, dtype=torch.float32, device=dev)
     _lib.check(lib.gnode_forward_f32(
         graph.handle, _lib.ptr(x2d), C.byref(p), _lib.host_ptr(dts), n_steps, m,
         _lib.host_ptr(out_rows) if out_rows is not None else None, n_out,
         _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(sol) if sol is not None else None,
+        _lib.ptr(keep) if keep is not None else None, keep.numel() * 4 if keep is not None else 0,
         rows, H, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    if sol is not None:
+        sol.gnode_keep = keep
     return out[0], out[1], out[2], sol
 
 
 def backward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray, method: str, out_rows, sol: torch.Tensor,
-             gS: torch.Tensor, gI: torch.Tensor, gR: torch.Tensor) -> dict:
+             gS: torch.Tensor, gI: torch.Tensor, gR: torch.Tensor, keep="auto") -> dict:
     """Adjoint-Euler parameter gradients (torchdiffeq odeint_adjoint semantics)
-    given the saved trajectory `sol` and the upstream gradients of S, I, R ([n_out, rows])."""
+    given the saved trajectory `sol` and the upstream gradients of S, I, R ([n_out, rows]).
+    keep: the forward's kept activations ("auto": ``sol.gnode_keep`` when `forward` attached it; None: recompute)."""
     if method != "euler":
         raise _lib.GnodeError("the adjoint backward is implemented for method='euler' (the reference's method)")
     lib = _lib.load()
@@ -118,9 +131,12 @@ def backward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarra
     grads = {k: torch.empty_like(params[k], memory_format=torch.contiguous_format) for k in PARAM_KEYS}
     ws = _workspace(lib.gnode_backward_workspace_bytes(graph.handle, rows, H), x2d.device)
     p, gp = pack_params({k: v.detach() for k, v in params.items()}), pack_params(grads)
+    if isinstance(keep, str):
+        keep = getattr(sol, "gnode_keep", None)
     _lib.check(lib.gnode_backward_f32(
         graph.handle, _lib.ptr(x2d), C.byref(p), _lib.host_ptr(dts), n_steps,
         _lib.host_ptr(out_rows) if out_rows is not None else None, n_out, _lib.ptr(_f32c(sol)),
+        _lib.ptr(keep) if keep is not None else None, keep.numel() * 4 if keep is not None else 0,
         _lib.ptr(_f32c(gS)), _lib.ptr(_f32c(gI)), _lib.ptr(_f32c(gR)), C.byref(gp), rows, H,
         _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
     return grads

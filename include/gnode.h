@@ -110,16 +110,26 @@ int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* 
  *              1 .. n_steps-1 carry A*Z_I(y_k) there instead -- the neighbour sums
  *              the adjoint backward would otherwise gather a second time -- and the
  *              last grid point's is left unwritten; other H repeat beta, gamma.
+ *   keep       NULL, or device buffer of keep_bytes >= gnode_forward_keep_bytes(...):
+ *              the KEPT ACTIVATIONS sigmoid(W y_k + b) of the S and I compartments at
+ *              every grid point, which the fused H = 64 path has in registers anyway
+ *              and gnode_backward_f32 then reads back instead of recomputing (three
+ *              of its seven 64x64 products per row and every sigmoid).  Opaque layout;
+ *              ignored when sol is NULL or gnode_forward_keep_bytes() is 0.  Outputs
+ *              and sol do not depend on whether keep is given.
  *   workspace  device, >= gnode_forward_workspace_bytes(g, rows, H, method) */
 size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t method);
 /* 1 when gnode_forward_f32 (method 0) on this graph stores A*Z_I(y_k) in the 4th slab of sol[k], 1 <= k <= n_steps-1
  * (see `sol` below), 0 when the 4th slab repeats beta, gamma at every grid point.  n_out: number of emitted grid
  * points (n_steps+1 when out_rows_host is NULL). */
 int gnode_sol_carries_neighbour_sums(gnode_graph_t g, int32_t H, int32_t n_steps, int32_t n_out);
+/* Size of the optional `keep` buffer of gnode_forward_f32 / gnode_backward_f32 (method 0), or 0 when this graph / H /
+ * grid takes a path that keeps nothing (then pass NULL).  2 * (n_steps + 1) * (rows + 1) * H floats on the H = 64 path. */
+size_t gnode_forward_keep_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t n_steps, int32_t n_out);
 int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
                       int32_t n_steps, int32_t method, const int32_t* out_rows_host, int32_t n_out,
-                      float* S, float* I, float* R, float* sol, int64_t rows, int32_t H,
-                      void* workspace, size_t workspace_bytes, void* stream);
+                      float* S, float* I, float* R, float* sol, float* keep, size_t keep_bytes,
+                      int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- backward -------------------------------------------------------------
  * The gradient the reference trains with: torchdiffeq's odeint_adjoint under
@@ -127,6 +137,9 @@ int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, co
  * SURVEY Appendix A) followed by autograd through the head and the encoder.
  *   sol          device [n_steps+1, 4*rows, H] saved by gnode_forward_f32 on THIS graph with the
  *                same n_steps / out_rows (its 4th slabs are read as described there)
+ *   keep         NULL, or the buffer the SAME gnode_forward_f32 call filled (then every
+ *                interval but the last reads the kept activations; gradients agree with
+ *                the keep = NULL path to fp32 rounding of the summation order)
  *   gS, gI, gR   device [n_out, rows] upstream gradients of the outputs
  *   grads        device pointers (same struct as the parameters) that RECEIVE
  *                dL/dparam (overwritten, not accumulated)
@@ -135,6 +148,7 @@ int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, co
 size_t gnode_backward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H);
 int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
                        int32_t n_steps, const int32_t* out_rows_host, int32_t n_out, const float* sol,
+                       const float* keep, size_t keep_bytes,
                        const float* gS, const float* gI, const float* gR, const gnode_params* grads,
                        int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -218,7 +232,7 @@ int gnode_meanfield_f64(gnode_graph_t g, const int32_t* seeds_host, int32_t n_se
 int gnode_profile_enable(int on);
 int gnode_profile_read(double* gather_ms, int64_t* gather_launches, double* mlp_ms, int64_t* mlp_launches);
 /* kind: 0 = Euler-step kernel, 1 = node-MLP kernel, 2 = backward interval kernel (H = 64), 3 = Monte-Carlo kernel;
- * one launch in 8 is sampled (the first of every 8 of its kind since gnode_profile_enable(1)). */
+ * one launch in 7 is sampled (the first of every 7 of its kind since gnode_profile_enable(1)). */
 int gnode_profile_read_kind(int32_t kind, double* ms, int64_t* launches);
 
 #ifdef __cplusplus

@@ -35,7 +35,7 @@ def test_binding_table_matches_header(lib):
 
 
 def test_version_and_sizes(lib):
-    assert lib.gnode_version() >= 200
+    assert lib.gnode_version() >= 210
     # workspace sizes depend on the graph (hub scratch): without a handle they answer 0 instead of guessing
     # (real sizes are exercised on the GPU: tests/test_gpu_abi.py)
     assert lib.gnode_rhs_workspace_bytes(None, 1000, 64) == 0

@@ -106,7 +106,12 @@ def test_backward_capture_and_two_streams(dev):
     for i in (0, 1):
         ref = ops.forward(g, xs[i], P, dts, "euler", None, True)
         torch.cuda.synchronize()
-        assert all(torch.equal(a, b) for a, b in zip(outs[i], ref))
+        assert all(torch.equal(a, b) for a, b in zip(outs[i][:3], ref[:3]))
+        rows = xs[i].shape[0]
+        assert torch.equal(outs[i][3][:-1], ref[3][:-1])                       # (the last grid point's 4th slab is left unwritten)
+        assert torch.equal(outs[i][3][-1, :3 * rows], ref[3][-1, :3 * rows])
+        ka, kb = (t[3].gnode_keep.view(len(dts) + 1, 2, rows + 1, H) for t in (outs[i], ref))   # kept activations
+        assert torch.equal(ka[:, 1], kb[:, 1]) and torch.equal(ka[:-1, 0, :rows], kb[:-1, 0, :rows])
     # backward captured on a fresh handle (first use of the backward entry point on it)
     g3 = DeviceGraph(rp, ci)
     S, I, R, sol = ops.forward(g3, xs[0], P, dts, "euler", None, True)

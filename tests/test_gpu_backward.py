@@ -60,14 +60,19 @@ def test_param_grads_vs_oracle(n, m, B, H, maxTime, deltaT, sub, dev, skewed=Fal
     x2d = torch.from_numpy(x).to(dev).reshape(B * n, 3 + H)
     dts = ops.step_sizes(grid)
     S, I, R, sol = ops.forward(g, x2d, params, dts, "euler", out_rows, want_sol=True)
-    got = ops.backward(g, x2d, params, dts, "euler", out_rows, sol, *[torch.from_numpy(a).to(dev) for a in gs])
-    for k in want:
-        assert got[k].shape == params[k].shape
-        if k == "linearS2.bias":
-            continue
-        err = _rel(got[k].cpu().numpy(), want[k])
-        # fp32 kernels vs a float64 yardstick; sums over up to rows*G terms
-        assert err <= 2e-4, f"{k}: rel err {err:.2e}"
+    gst = [torch.from_numpy(a).to(dev) for a in gs]
+    # both forms of the sweep: over the forward's kept activations (where this path keeps any), and recomputing them
+    variants = {"kept": ops.backward(g, x2d, params, dts, "euler", out_rows, sol, *gst)}
+    if sol.gnode_keep is not None:
+        variants["recomputed"] = ops.backward(g, x2d, params, dts, "euler", out_rows, sol, *gst, keep=None)
+    for name, got in variants.items():
+        for k in want:
+            assert got[k].shape == params[k].shape
+            if k == "linearS2.bias":
+                continue
+            err = _rel(got[k].cpu().numpy(), want[k])
+            # fp32 kernels vs a float64 yardstick; sums over up to rows*G terms
+            assert err <= 2e-4, f"{name} {k}: rel err {err:.2e}"
     # linearS2.bias: softmax is shift invariant -> exact gradient 0; ours must be ~0 relative to the others
     assert abs(float(got["linearS2.bias"].cpu())) <= 1e-4 * max(1.0, float(np.abs(want["linearS2.weight"]).max()))
 
@@ -273,3 +278,54 @@ def test_backward_full_size_properties(dev):
         scale = float(max(r1[k].abs().max(), r2[k].abs().max())) + 1e-30
         assert float((rd[k] - 2 * r1[k]).abs().max()) <= 2e-5 * scale, k       # homogeneity (x2 is exact up to reduction order)
         assert float((rs[k] - (r1[k] + r2[k])).abs().max()) <= 2e-4 * scale, k  # additivity, fp32 sums over 75k rows x 6 points
+
+
+def test_kept_activations_are_the_forwards_and_optional(dev):
+    """The `keep` buffer of gnode_forward_f32 (include/gnode.h): outputs and trajectory do not depend on whether it is given;
+    its tables ARE sigmoid(W y_k + b) of the trajectory's S / I rows (checked against torch on the saved rows); and the
+    backward over it agrees with the recomputing backward to fp32 round-off -- on a graph with hub rows and a ragged
+    last tile, with a subsampled output grid."""
+    import torch
+    import gnode_oracle as O
+    from gnode import _lib, ops
+    from gnode.graph import DeviceGraph
+    n, B, H, maxTime, deltaT = 2003, 3, 64, 6, 0.5
+    rp, ci, _ = O.chung_lu_graph(n, 24000, seed=9)
+    P = {k: torch.from_numpy(v).to(dev) for k, v in O.init_params(H, seed=5).items()}
+    x = torch.from_numpy(O.make_samples(n, B, H, seed=6)).to(dev).reshape(B * n, 3 + H)
+    g = DeviceGraph(rp, ci)
+    assert int(np.diff(rp).max()) > 96                         # hub rows present
+    dts = ops.step_sizes(ops.time_grid(maxTime, deltaT))
+    rows_out = ops.subsample_rows(maxTime, deltaT)
+    G, rows = len(dts) + 1, B * n
+    S1, I1, R1, sol1 = ops.forward(g, x, P, dts, "euler", rows_out, want_sol=True)
+    S0, I0, R0, sol0 = ops.forward(g, x, P, dts, "euler", rows_out, want_sol=True, want_keep=False)
+    keep = sol1.gnode_keep
+    assert keep is not None and sol0.gnode_keep is None
+    assert keep.numel() * 4 == _lib.load().gnode_forward_keep_bytes(g.handle, rows, H, G - 1, len(rows_out))
+    for a, b in ((S1, S0), (I1, I0), (R1, R0)):
+        assert torch.equal(a, b)
+    assert torch.equal(sol1[:, :3 * rows], sol0[:, :3 * rows])
+    assert torch.equal(sol1[1:G - 1, 3 * rows:], sol0[1:G - 1, 3 * rows:])          # the kept neighbour sums
+    kv = keep.view(G, 2, rows + 1, H)
+    W, b = P["odefunc.linear.weight"], P["odefunc.linear.bias"]
+    for k in range(G - 1):                                                        # Z_S(y_k): steps 0 .. G-2 evaluate it
+        z = torch.sigmoid(sol1[k, :rows].double() @ W.T.double() + b.double())
+        assert float((kv[k, 0, :rows].double() - z).abs().max()) <= 2e-5     # structural check (right table, right grid point): fp32 pre-activations reach tens on this hub graph
+    for k in range(G):                                                            # Z_I(y_k): every grid point's gather table
+        z = torch.sigmoid(sol1[k, rows:2 * rows].double() @ W.T.double() + b.double())
+        assert float((kv[k, 1, :rows].double() - z).abs().max()) <= 2e-5
+        assert float(kv[k, 1, rows].abs().max()) == 0.0                           # the table's zero row
+    gs = [torch.randn(len(rows_out), rows, device=dev) for _ in range(3)]
+    a = ops.backward(g, x, P, dts, "euler", rows_out, sol1, *gs)
+    r = ops.backward(g, x, P, dts, "euler", rows_out, sol1, *gs, keep=None)
+    r0 = ops.backward(g, x, P, dts, "euler", rows_out, sol0, *gs)
+    for k in a:
+        assert torch.equal(r[k], r0[k]), k
+        if k == "linearS2.bias":
+            continue
+        scale = float(r[k].abs().max()) + 1e-30
+        assert float((a[k] - r[k]).abs().max()) <= 2e-5 * scale, (k, float((a[k] - r[k]).abs().max()) / scale)
+    # a short keep buffer is refused, not overrun
+    with pytest.raises(_lib.GnodeError):
+        ops.backward(g, x, P, dts, "euler", rows_out, sol1, *gs, keep=keep[: keep.numel() // 2])
