@@ -45,3 +45,28 @@ def forward_with_grad(graph, x2d, params, dts, method="euler", out_rows=None):
         return S, I, R
     keys = tuple(params.keys())
     return _GNODEForward.apply(graph, x2d, dts, method, out_rows, keys, *[params[k] for k in keys])
+
+
+class _L1LossSum(torch.autograd.Function):
+    """sum |cat(S, I, R)[rows, T, 3][:, t0:, :] - y[:, t0:, :]| with its gradient from one kernel (csrc/gnode_loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, S, I, R, y, t0):
+        need_grad = any(ctx.needs_input_grad[:3])
+        total, sgn = ops.l1_loss_sum(S, I, R, y, t0, want_sign=need_grad)
+        ctx.shape = S.shape
+        if need_grad:
+            ctx.save_for_backward(sgn)
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        (sgn,) = ctx.saved_tensors
+        gs = (sgn * g.to(torch.float32)).view(3, *ctx.shape)
+        return gs[0], gs[1], gs[2], None, None
+
+
+def l1_loss_sum(S, I, R, y, t0=1):
+    """The reference's loss numerator (ode_nn_ngraph_sim.py:230-234): S, I, R are the model's [T, rows(, 1)] outputs,
+    y the labels [rows, T, 3] (fp32 or fp64); returns a float64 scalar.  Divide by rows * (T - t0) * 3 for L1Loss's mean."""
+    return _L1LossSum.apply(S, I, R, y, t0)

@@ -140,3 +140,25 @@ def backward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarra
         _lib.ptr(_f32c(gS)), _lib.ptr(_f32c(gI)), _lib.ptr(_f32c(gR)), C.byref(gp), rows, H,
         _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
     return grads
+
+
+def l1_loss_sum(S: torch.Tensor, I: torch.Tensor, R: torch.Tensor, y: torch.Tensor, t0: int = 1, want_sign: bool = True):
+    """sum over rows, t >= t0, c of |pred_c[t, row] - y[row, t, c]| as a float64 device scalar, and (want_sign)
+    sign(pred - y) as fp32 [3, T, rows] -- the loss of ode_nn_ngraph_sim.py:230-234 and its gradient in one launch."""
+    lib = _lib.load()
+    S, I, R = (_f32c(t.detach()) for t in (S, I, R))
+    T = int(S.shape[0])
+    rows = S.numel() // max(T, 1)
+    if y.dtype not in (torch.float32, torch.float64):
+        y = y.to(torch.float32)
+    y = y.detach().contiguous()
+    if tuple(y.shape) != (rows, T, 3) or any(t.numel() != T * rows for t in (I, R)):
+        raise _lib.GnodeError(f"l1_loss_sum: outputs {tuple(S.shape)} vs labels {tuple(y.shape)}")
+    dev = S.device
+    total = torch.empty((), dtype=torch.float64, device=dev)
+    sgn = torch.empty((3, T, rows), dtype=torch.float32, device=dev) if want_sign else None
+    ws = _workspace(lib.gnode_l1_loss_workspace_bytes(), dev)
+    _lib.check(lib.gnode_l1_loss_f32(_lib.ptr(S), _lib.ptr(I), _lib.ptr(R), _lib.ptr(y), int(y.dtype == torch.float64), rows, T,
+                                     int(t0), _lib.ptr(total), _lib.ptr(sgn) if sgn is not None else None, _lib.ptr(ws),
+                                     ws.numel(), _lib.stream_ptr()))
+    return total, sgn

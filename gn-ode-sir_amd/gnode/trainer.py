@@ -195,9 +195,10 @@ class Runner:
 
     def _loss_sum(self, x, y):
         S, I, R = self.model(x, out_rows=self.rows)
-        pred = torch.cat((S, I, R), -1).transpose(0, 1)[:, 1:, :]       # [rows, T-1, 3], t = 0 excluded (:234)
-        tgt = y[:, 1:, :]
-        return (pred.to(tgt.dtype) - tgt).abs().sum()
+        # L1 over cat(S, I, R)[rows, T, 3][:, 1:, :] (t = 0 excluded, :234) and its gradient: one kernel instead of the
+        # cat / transpose / convert / subtract / abs / sum chain and its six backward launches
+        from .autograd import l1_loss_sum
+        return l1_loss_sum(S, I, R, y, 1)
 
     def _graphed_backward(self, x, y, gcount):
         """Replay (capturing on first use) forward + L1 + backward for this batch shape; returns the loss sum."""

@@ -223,6 +223,21 @@ int gnode_meanfield_f64(gnode_graph_t g, const int32_t* seeds_host, int32_t n_se
                         const double* t_out_host, int32_t n_out, double rtol, double atol, double* outI, double* outS,
                         double* outR, int64_t* steps_host, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- loss ------------------------------------------------------------------
+ * The training loss of ode_nn_ngraph_sim.py:230-234 (multi-graph: ode_nn_ngraphs.py:199-203) and its gradient in one
+ * pass: pred = cat(S, I, R)[rows, T, 3] against the labels y, t = 0 excluded,
+ *     *loss_sum = sum_{row, t >= t0, c} |pred_c[t, row] - y[row, t, c]|        (float64; L1Loss's mean = sum / count)
+ *     sgn[c, t, row] = sign(pred_c[t, row] - y[row, t, c]), 0 for t < t0       (= d loss_sum / d pred; may be NULL)
+ *   S, I, R   device [T, rows] fp32 (gnode_forward_f32's outputs)
+ *   y         device [rows, T, 3], fp32 or fp64 (y_is_f64); the difference is taken in y's type
+ *   loss_sum  device double;  sgn: device [3, T, rows] fp32 or NULL
+ *   workspace device, >= gnode_l1_loss_workspace_bytes()
+ * Deterministic (fixed-order reduction), asynchronous on `stream`. */
+size_t gnode_l1_loss_workspace_bytes(void);
+int gnode_l1_loss_f32(const float* S, const float* I, const float* R, const void* y, int32_t y_is_f64, int64_t rows,
+                      int32_t T, int32_t t0, double* loss_sum, float* sgn, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
 /* ---- instrumentation -------------------------------------------------------
  * While enabled, every launch of the two step kernels (0: gather + SIR update +
  * read-out, 1: node MLP) is bracketed by HIP events on the launch stream;

@@ -246,3 +246,31 @@ def test_runner_loss_matches_reference_epoch_loops(dev):
         te, per = run.evaluate(xs, ys, 2)
         assert abs(te - float(d["test_loss"])) <= 1e-6
         assert np.max(np.abs(np.asarray(per) - d["test_all"])) <= 1e-6
+
+
+@pytest.mark.parametrize("T,rows,t0,ydt", [(30, 1000, 1, "float32"), (30, 1000, 1, "float64"), (5, 7, 1, "float32"),
+                                           (200, 130, 1, "float64"), (20, 34 * 5, 0, "float32"), (3, 4097, 2, "float64")])
+def test_fused_l1_loss_matches_the_torch_expression(T, rows, t0, ydt, dev):
+    """csrc/gnode_loss.hip against the loss expression the reference evaluates with torch ops
+    (ode_nn_ngraph_sim.py:230-234: cat, transpose, [:, 1:, :], L1Loss) and torch autograd's gradient of it: value to
+    float64 round-off of the summation order, gradient exactly; ragged row blocks, label rows longer than a few per
+    LDS block, fp32 and fp64 labels; two runs agree bitwise."""
+    import torch
+    from gnode.autograd import l1_loss_sum
+    gen = torch.Generator().manual_seed(T * 1000 + rows)
+    S, I, R = (torch.rand(T, rows, 1, generator=gen).to(dev).requires_grad_(True) for _ in range(3))
+    y = torch.rand(rows, T, 3, generator=gen, dtype=getattr(torch, ydt)).to(dev)
+    with torch.no_grad():
+        y[::3, :, 0] = S[:, ::3, 0].T.to(y.dtype)                     # exact ties: sign 0, as torch's abs backward
+    pred = torch.cat((S, I, R), -1).transpose(0, 1)[:, t0:, :]
+    want = (pred.to(y.dtype) - y[:, t0:, :]).abs().double().sum()
+    gw = torch.autograd.grad(want * 0.37, (S, I, R))
+    got = l1_loss_sum(S, I, R, y, t0)
+    assert got.dtype == torch.float64 and abs(float(got.detach()) - float(want.detach())) <= 1e-12 * float(want.detach())
+    gg = torch.autograd.grad(got * 0.37, (S, I, R))
+    for a, b in zip(gg, gw):
+        assert a.shape == b.shape and torch.equal(a, b.to(a.dtype))
+    again = l1_loss_sum(S, I, R, y, t0)
+    assert float(again.detach()) == float(got.detach())
+    with torch.no_grad():                                              # evaluation: no sign tensor is produced
+        assert float(l1_loss_sum(S, I, R, y, t0)) == float(got.detach())
