@@ -131,7 +131,7 @@ def bench_train(lib, dev, n, m, B, H, maxTime, deltaT, reps):
            "node_timesteps_per_s": B * n * n_steps / dt, "loss_finite": bool(torch.isfinite(loss).item()),
            "fwd_step_kernel_avg_us": fwd_ms / max(fwd_n, 1) * 1e3, "bwd_interval_kernel_avg_us": bwd_ms / max(bwd_n, 1) * 1e3}
     if bwd_n:
-        # backward interval kernel (k_bwd_fused64), one sample-interval: DESIGN.md section 7
+        # backward interval kernel (k_bwd_kept64, both instances averaged), one sample-interval: DESIGN.md section 7
         sb = bwd_interval_bytes(n, nnz, H)
         for k in ("algorithmic", "compulsory"):
             out[f"bwd_{k}_bytes_per_launch"] = sb[k] * B
@@ -142,14 +142,14 @@ def bench_train(lib, dev, n, m, B, H, maxTime, deltaT, reps):
 
 
 def bwd_interval_bytes(n, nnz, H):
-    """One sample, one interval of the fused adjoint kernel (k_bwd_fused64<.,.,false>): the A q
-    gather (A Z_I(y_i) is read back from the slab the forward kept) plus the slab rows it reads and writes:
-    reads a_S, a_I, a_R (3) + y_i S, I rows (2) + kept A Z_I row (1) + y_{i-1} S row (1) + y_{i-1} I, R rows at output grid
-    points (every second interval with the fused subsample: 1 on average); writes a_S, a_I (2) + a_R at output points (0.5)
+    """One sample, one interval of the adjoint kernel over kept activations (k_bwd_kept64): the A q
+    gather plus the slab rows it reads and writes.  Reads a_S, a_I, a_R (3) + y_i S, I rows (2) + the forward's kept
+    Z_S(y_i), Z_I(y_i) (2) + kept A Z_I(y_i) (1) + kept Z_S(y_{i-1}) (1) + y_{i-1} S, I, R rows at output grid points
+    (every second interval with the fused subsample: 1.5 on average); writes a_S, a_I (2) + a_R at output points (0.5)
     + the next interval's q table (1)."""
     slab = n * H * 4
-    slabs = 3 + 2 + 1 + 1 + 1 + 2 + 0.5 + 1
-    csr = nnz * 4 + (n + 1) * 4
+    slabs = 3 + 2 + 2 + 1 + 1 + 1.5 + 2 + 0.5 + 1
+    csr = nnz * 4 + n * 20 * 4                  # column ids + row headers
     return {"algorithmic": csr + nnz * H * 4 + slabs * slab, "compulsory": csr + slabs * slab}
 
 
