@@ -639,6 +639,7 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__
     const float* YpI = Yprev + slab; const float* YpR = Yprev + 2 * slab;
     const int lr = w * 4 + g, ro = lr * TS + 4 * sub;
     const unsigned lane_b = 16u * sub;
+    constexpr bool NT = true;                      // streamed rows are non-temporal: the L2 is for the q table the gather re-reads
     constexpr bool head = HEAD;                    // compile-time: the accumulators of the head's parameter gradients exist only here
     HeadAcc hacc;
 #pragma unroll
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__
     int t = q_lo + blockIdx.x / xq;
     head_of(t, cur);
     {
-        const float4 ys = ld4o(Ysol, cur.row * 256u + lane_b), yi = ld4o(YIs, cur.row * 256u + lane_b);
+        const float4 ys = ld4so<NT>(Ysol, cur.row * 256u + lane_b), yi = ld4so<NT>(YIs, cur.row * 256u + lane_b);
         GN_ISSUE8(cur.mine, 0)
         *reinterpret_cast<float4*>(&Yt[0][ro]) = ys; *reinterpret_cast<float4*>(&Yt[1][ro]) = yi;
     }
@@ -700,8 +701,8 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__
         const bool valid = cur.valid;
         const unsigned off = cur.row * 256u + lane_b;
         const float bt = valid ? beta[cur.row] : 0.f, gm = gamma[cur.row];
-        float4 aS = ld4o(aSp, off), aI = ld4o(aIp, off), aR = ld4o(aRp, off);
-        const float4 zs = ld4o(ZSk, off), zi = ld4o(ZIk, off), ai = ld4o(AIk, off);
+        float4 aS = ld4so<NT>(aSp, off), aI = ld4so<NT>(aIp, off), aR = ld4so<NT>(aRp, off);
+        const float4 zs = ld4so<NT>(ZSk, off), zi = ld4so<NT>(ZIk, off), ai = ld4so<NT>(AIk, off);
         float4 gq = zero4();
         if (hubidx) {                                  // uniform: hub rows arrive pre-summed (their gather reads zero rows)
             const float4 hq = ld4o(GQhub, cur.hoff + lane_b);
@@ -737,12 +738,12 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__
         float4 zsp = zero4();
         float4 y[3] = {zero4(), zero4(), zero4()};
         float gout[3] = {0.f, 0.f, 0.f};
-        if (do_next) zsp = ld4o(ZSp, off);
+        if (do_next) zsp = ld4so<NT>(ZSp, off);
         if (head) {
-            y[0] = ld4o(Yprev, off); y[1] = ld4o(YpI, off); y[2] = ld4o(YpR, off);
+            y[0] = ld4so<NT>(Yprev, off); y[1] = ld4so<NT>(YpI, off); y[2] = ld4so<NT>(YpR, off);
             gout[0] = valid ? gS[cur.row] : 0.f; gout[1] = valid ? gI[cur.row] : 0.f; gout[2] = valid ? gR[cur.row] : 0.f;
         }
-        const float4 ysn = ld4o(Ysol, nxt.row * 256u + lane_b), yin = ld4o(YIs, nxt.row * 256u + lane_b);
+        const float4 ysn = ld4so<NT>(Ysol, nxt.row * 256u + lane_b), yin = ld4so<NT>(YIs, nxt.row * 256u + lane_b);
         GN_ISSUE8(nxt.mine, 0)
         // gW += dpre^T y (contraction over the tile's 16 rows), then g_Y = dpre W: one matrix phase
 #pragma unroll
@@ -773,12 +774,12 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__
 #pragma unroll
             for (int k = 0; k < 4; ++k) w3v[k] = ld4g(w3 + k * 64 + 4 * sub);      // L1-resident
             head_vjp64(y, gout, w3v, b3, w2, b2, aS, aI, aR, hacc);                 // padding rows: gout = 0 adds nothing
-            if (valid) st4o(a + 2 * slab, off, aR);
+            if (valid) st4so<NT>(a + 2 * slab, off, aR);
         }
         if (valid) {
-            st4o(a, off, aS); st4o(a + slab, off, aI);
+            st4so<NT>(a, off, aS); st4so<NT>(a + slab, off, aI);
             if (do_next)
-                st4o(Qn, off, make_float4(bt * (aI.x - aS.x) * zsp.x, bt * (aI.y - aS.y) * zsp.y,
+                st4so<NT>(Qn, off, make_float4(bt * (aI.x - aS.x) * zsp.x, bt * (aI.y - aS.y) * zsp.y,
                                           bt * (aI.z - aS.z) * zsp.z, bt * (aI.w - aS.w) * zsp.w));
         }
         *reinterpret_cast<float4*>(&Yt[0][ro]) = ysn; *reinterpret_cast<float4*>(&Yt[1][ro]) = yin;

@@ -24,11 +24,6 @@
 #include "gnode_mfma64.h"
 #include <algorithm>
 
-template <bool NT>
-__device__ __forceinline__ float4 ld4so(const float* b, unsigned off) { return ld4s<NT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(b) + off)); }
-template <bool NT>
-__device__ __forceinline__ void st4so(float* b, unsigned off, float4 v) { st4s<NT>(reinterpret_cast<float*>(reinterpret_cast<char*>(b) + off), v); }
-
 // --------------------------------------------------------------------------- k_mlp64
 __global__ __launch_bounds__(256) void k_mlp64(const float* __restrict__ X, const float* __restrict__ W,
                                                const float* __restrict__ bias, float* __restrict__ Z, long nrows) {

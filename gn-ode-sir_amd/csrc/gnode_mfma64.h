@@ -35,6 +35,12 @@ __device__ __forceinline__ void st4s(float* p, float4 v) {
     else st4g(p, v);
 }
 
+// the same through a uniform base + 32-bit byte offset
+template <bool NT>
+__device__ __forceinline__ float4 ld4so(const float* b, unsigned off) { return ld4s<NT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(b) + off)); }
+template <bool NT>
+__device__ __forceinline__ void st4so(float* b, unsigned off, float4 v) { st4s<NT>(reinterpret_cast<float*>(reinterpret_cast<char*>(b) + off), v); }
+
 // ---- DPP helpers: a 16-lane group is exactly one DPP row -----------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
