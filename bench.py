@@ -136,6 +136,18 @@ def bench_train(lib, dev, n, m, B, H, maxTime, deltaT, reps):
         for k in ("algorithmic", "compulsory"):
             out[f"bwd_{k}_bytes_per_launch"] = sb[k] * B
             out[f"bwd_{k}_frac_of_hbm_peak"] = sb[k] * B / (bwd_ms / bwd_n * 1e-3) / 1e9 / HBM_PEAK_GBS
+        # measured L2<->fabric traffic of the training kernels, from the committed PMC passes (same provenance rules as the
+        # step kernel's: a file, labelled as such)
+        pm = os.path.join(ROOT, "profiles", "pmc_train_latest.json")
+        if os.path.exists(pm) and (n, nnz, B, H, maxTime) == (75000, 1000000, 4, 64, 30):
+            try:
+                d = json.load(open(pm))
+                out["measured_fabric_traffic_bytes_per_launch"] = {k.replace("void ", ""): v["traffic_bytes_per_launch"]
+                                                                   for k, v in d["kernels"].items()}
+                out["traffic_source"] = {"file": "profiles/pmc_train_latest.json", "measured_in_this_run": False,
+                                         "collected": d.get("collected"), "tree": d.get("tree")}
+            except Exception:
+                pass
     del model, x, y
     torch.cuda.empty_cache()
     return out
