@@ -41,6 +41,8 @@ def test_version_and_sizes(lib):
     assert lib.gnode_rhs_workspace_bytes(None, 1000, 64) == 0
     assert lib.gnode_forward_workspace_bytes(None, 1000, 64, 0) == 0
     assert lib.gnode_backward_workspace_bytes(None, 1000, 64) == 0
+    assert lib.gnode_forward_keep_bytes(None, 1000, 64, 59, 60) == 0        # nothing is kept without a graph either
+    assert lib.gnode_l1_loss_workspace_bytes() >= 8                          # graph-independent: one double per workgroup
 
 
 def test_product_path_has_no_cpu_fallback():
