@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -93,7 +94,7 @@ def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray
     ws = workspace if (workspace is not None and workspace.numel() >= need) else _workspace(need, dev)
     p = pack_params(params)
     keep = None
-    if sol is not None and want_keep and m == 0:
+    if sol is not None and want_keep and m == 0 and os.environ.get("GNODE_KEEP", "1") != "0":
         kb = lib.gnode_forward_keep_bytes(graph.handle, rows, H, n_steps, n_out)
         if kb:
             keep = torch.empty(kb // 4, dtype=torch.float32, device=dev)

@@ -329,3 +329,43 @@ def test_kept_activations_are_the_forwards_and_optional(dev):
     # a short keep buffer is refused, not overrun
     with pytest.raises(_lib.GnodeError):
         ops.backward(g, x, P, dts, "euler", rows_out, sol1, *gs, keep=keep[: keep.numel() // 2])
+
+
+@pytest.mark.parametrize("name", ["adjoint_karate_H64_T20", "adjoint_er200_H64_T6", "adjoint_loops40_H8_T5"])
+def test_training_gradient_vs_reference_classes(name, dev):
+    """The whole training gradient through the PRODUCT's call surface (ODEBlock mirror -> fused forward, the L1 loss
+    op, the adjoint backward) against what the REFERENCE's ODEBlock / ODEfunc / loss expression produced under the
+    restated adjoint rule, in float64 (tests/golden/make_golden_adjoint.py).  karate: the one-launch tiny paths;
+    er200: the tiled path over kept activations; loops40 (H = 8, self-loops): the generic path."""
+    import os
+    import torch
+    import scipy.sparse as sp
+    import gnode_oracle as O
+    from gnode import synth
+    from gnode.autograd import l1_loss_sum
+    from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
+    from gnode import ops
+    from golden.labels import closed_form_labels
+    d = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")))
+    n, B, H, maxTime, deltaT = int(d["n"]), int(d["B"]), int(d["H"]), int(d["maxTime"]), float(d["deltaT"])
+    rp, ci = O.csr_from_edges(n, d["edges"])
+    A = sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n))
+    P = synth.linear_params(H, seed=int(d["param_seed"]))
+    model = ODEBlock(maxTime, deltaT, n, [0], H, ODEfunc(A, 0.2, 0.1, H, dev), dev).to(dev)
+    model.load_state_dict({**model.state_dict(), **{k: torch.from_numpy(v) for k, v in P.items()}})
+    x = torch.from_numpy(synth.samples(n, B, H, seed=int(d["sample_seed"]))).to(dev)
+    y = torch.from_numpy(closed_form_labels(B, n, maxTime).reshape(B * n, maxTime, 3)).to(dev)
+    S, I, R = model(x, out_rows=ops.subsample_rows(maxTime, deltaT))
+    for c, got in zip("SIR", (S, I, R)):                                      # forward: the reference's float64 outputs
+        assert float((got[..., 0].double().cpu() - torch.from_numpy(d[c])).abs().max()) <= 1e-5
+    loss = l1_loss_sum(S, I, R, y, 1) / (B * n * (maxTime - 1) * 3)
+    assert abs(float(loss.detach()) - float(d["loss"])) <= 1e-6
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k in P:
+        want = d["G:" + k]
+        if k == "linearS2.bias":                                              # exact gradient 0 (softmax shift invariance)
+            assert float(named[k].grad.abs().max()) <= 1e-6
+            continue
+        err = _rel(named[k].grad.cpu().numpy(), want)
+        assert err <= 2e-4, f"{k}: rel err {err:.2e}"

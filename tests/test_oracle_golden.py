@@ -150,13 +150,19 @@ def test_meanfield_oracle_matches_reference_vectors(name):
 
 # ---- full horizon at the BASELINE graph sizes (tests/golden/make_golden_fullsize.py): the reference's own fp32
 # output over 59 Euler steps on fb-social- and wiki-vote-sized graphs pins both CPU restatements there.
-def _full_inputs(d):
-    """rebuild graph / weights / sample from the stored seeds (gnode/synth.py is numpy + scipy only)"""
+def _synth():
+    """gnode/synth.py on its own (numpy + scipy only; importing the gnode package would pull in torch and the library)"""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
         "_synth", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gn-ode-sir_amd", "gnode", "synth.py"))
     synth = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(synth)
+    return synth
+
+
+def _full_inputs(d):
+    """rebuild graph / weights / sample from the stored seeds"""
+    synth = _synth()
     n, H = int(d["n"]), int(d["H"])
     rp, ci = synth.er_csr(n, int(d["m"]), seed=int(d["graph_seed"]))
     return rp, ci, synth.linear_params(H, seed=int(d["param_seed"])), synth.samples(n, 1, H, seed=int(d["sample_seed"]))
@@ -191,3 +197,31 @@ def test_full_horizon_matches_reference(path):
     y = closed_form_labels(1, n, maxTime)
     loss = O.l1_loss(S, I, R, y, maxTime, deltaT)
     assert abs(loss - float(d["loss"])) <= 1e-6
+
+
+@pytest.mark.parametrize("path", _cases("adjoint_"), ids=os.path.basename)
+def test_adjoint_restatement_matches_reference_classes(path):
+    """The oracle's adjoint-Euler gradient (autograd over the oracle's OWN restatement of the RHS, head and encoder)
+    against the gradients the REFERENCE classes produced under the same integrator rule
+    (tests/golden/make_golden_adjoint.py: reference ODEBlock / ODEfunc / loss expression, float64): pins every
+    derivative on the training path except torchdiffeq's adjoint rule itself, which both sides restate."""
+    from golden.labels import closed_form_labels
+    synth = _synth()
+    d = dict(np.load(path))
+    n, B, H, maxTime, deltaT = int(d["n"]), int(d["B"]), int(d["H"]), int(d["maxTime"]), float(d["deltaT"])
+    rp, ci = O.csr_from_edges(n, d["edges"])
+    P = synth.linear_params(H, seed=int(d["param_seed"]))
+    x = synth.samples(n, B, H, seed=int(d["sample_seed"]))
+    y = closed_form_labels(B, n, maxTime).reshape(B * n, maxTime, 3)
+    rows = np.asarray([int(i / deltaT) for i in range(maxTime)])
+    pred = np.stack([d[c] for c in "SIR"], -1)                                    # [T, rows, 3]: the reference's outputs
+    diff = pred - y.transpose(1, 0, 2)
+    diff[0] = 0.0                                                                 # t = 0 excluded (:234)
+    N = B * n * (maxTime - 1) * 3
+    loss = np.abs(diff).sum() / N
+    assert abs(loss - float(d["loss"])) <= 1e-9
+    g = np.sign(diff) / N
+    got = O.adjoint_grads_torch(x, P, rp, ci, maxTime, deltaT, g[..., 0], g[..., 1], g[..., 2], out_rows=rows, dtype="float64")
+    for k, v in got.items():
+        want = d["G:" + k]
+        assert np.max(np.abs(np.asarray(v) - want)) <= 1e-9 * (np.max(np.abs(want)) + 1e-12) + 1e-15, k
