@@ -357,7 +357,7 @@ def test_training_gradient_vs_reference_classes(name, dev):
     y = torch.from_numpy(closed_form_labels(B, n, maxTime).reshape(B * n, maxTime, 3)).to(dev)
     S, I, R = model(x, out_rows=ops.subsample_rows(maxTime, deltaT))
     for c, got in zip("SIR", (S, I, R)):                                      # forward: the reference's float64 outputs
-        assert float((got[..., 0].double().cpu() - torch.from_numpy(d[c])).abs().max()) <= 1e-5
+        assert float((got.detach()[..., 0].double().cpu() - torch.from_numpy(d[c])).abs().max()) <= 1e-5
     loss = l1_loss_sum(S, I, R, y, 1) / (B * n * (maxTime - 1) * 3)
     assert abs(float(loss.detach()) - float(d["loss"])) <= 1e-6
     loss.backward()
