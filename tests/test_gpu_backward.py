@@ -33,6 +33,8 @@ def _rel(a, b):
     (62, 159, 5, 64, 5, 0.5, False),       # dolphins-sized, two row tiles
     (24, 200, 2, 64, 3, 0.5, False),       # dense: rows longer than the 16 neighbour ids cached in registers
     (33, 60, 2, 64, 1, 0.5, False),        # a single grid point: head + encoder only, no interval
+    (150, 700, 2, 64, 1, 0.5, False),      # tiled path, two grid points: the only interval is the last one (recomputing kernel)
+    (150, 700, 2, 64, 1.5, 0.5, False),    # three grid points: one interval over kept activations, do_next = 0
     (8, 12, 800, 64, 2, 0.5, False),       # more samples than partial-gradient slots: tiny graphs on the tiled path
     (30, 60, 2, 4, 3, 0.5, False),         # H = 4: one lane per row in the generic one-launch backward
     (30, 60, 2, 24, 3, 0.5, True),         # H = 24: lane groups of 8 with two idle lanes
