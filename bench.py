@@ -337,8 +337,9 @@ def main():
                          "random_row_read_ceiling_gbps (MI355X_MICROARCH.md, 151 MB table)": list(GATHER_CEILING_GBS)},
                      "limiter": "L2<->fabric random-row read rate: the per-XCD 19.2 MB Z_I table is 5x the 4 MB L2, 83 % of neighbour-row "
                                 "reads miss it and are served by the Infinity Cache; the vector L1s sit at their outstanding-miss limit "
-                                "(TCP_PENDING_STALL 72 % of cycles), fabric reads run at the guide's random-row ceiling; occupancy 3 vs 4 "
-                                "workgroups per CU, +-6 % read bytes and the read-out's VALU do not move the launch time (DESIGN.md section 4)"},
+                                "(TCP_PENDING_STALL ~65 % of cycles), fabric reads run at the guide's random-row ceiling; occupancy 3 vs 4 "
+                                "workgroups per CU, +-6 % read bytes and the read-out's VALU do not move the launch time, and even a gather "
+                                "working set cut to a quarter (4.8 MB per XCD) leaves 88 % of it (DESIGN.md section 4.1)"},
     }
 
     single = rank == 0 and world == 1
