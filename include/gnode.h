@@ -13,8 +13,8 @@
  *     over torch tensors' data_ptr()); the library never frees or retains them
  *     past the call.  "host" pointers are ordinary memory, read before return.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
- *     All work is enqueued on it.  gnode_rhs_f32, gnode_forward_f32 and
- *     gnode_backward_f32 allocate nothing, synchronise nothing and keep nothing in
+ *     All work is enqueued on it.  gnode_rhs_f32, gnode_forward_f32,
+ *     gnode_backward_f32 and gnode_l1_loss_f32 allocate nothing, synchronise nothing and keep nothing in
  *     the graph handle: every byte of scratch (including the partial sums of long
  *     "hub" rows) is carved from the caller's workspace, so they can be captured
  *     into a hipGraph on first use and one handle may serve several streams (each
