@@ -22,7 +22,8 @@ struct PartLayout {
 bool gn_tiny_bwd64_ok(const gnode_graph_s* g, long rows, int H, int n_steps);
 int gn_launch_tiny_bwd64(const gnode_graph_s* g, long rows, const float* x, const gnode_params* p, const float* dt_host,
                          int n_steps, const int32_t* out_rows_host, int n_out, const float* sol, const float* gS,
-                         const float* gI, const float* gR, float* part, hipStream_t st);
+                         const float* gI, const float* gR, float* part,
+                         const float* keep /* the forward's kept activations, or null = recompute */, hipStream_t st);
 
 // H = 128: a += dt dpre W, gW, gb on the matrix cores (gnode_h128.hip); raises *slots_used to its grid size
 int gn_launch_bwd_mlp128(const gnode_graph_s* g, const float* dpre, const float* Ysol, const float* W, float dt, float* a, long rows,

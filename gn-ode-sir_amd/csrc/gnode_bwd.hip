@@ -1147,7 +1147,14 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     const bool tiny = gn_tiny_bwd64_ok(g, rows, H, n_steps);
     if (tiny) {
         // graphs that fit one workgroup: the whole sweep is one launch writing slot b for sample b (gnode_bwd_tiny.hip)
-        if (int e = gn_launch_tiny_bwd64(g, rows, x, p, dt_host, n_steps, out_rows_host, n_out, sol, gS, gI, gR, part, st)) return e;
+        const size_t keep_need = gnode_forward_keep_bytes(g, rows, H, n_steps, out_rows_host ? n_out : n_steps + 1);
+        if (keep && keep_need > 0 && keep_bytes < keep_need) {
+            gnode_set_error("gnode_backward_f32: keep buffer %zu < %zu", keep_bytes, keep_need);
+            return GNODE_ERR_WORKSPACE;
+        }
+        if (int e = gn_launch_tiny_bwd64(g, rows, x, p, dt_host, n_steps, out_rows_host, n_out, sol, gS, gI, gR, part,
+                                         keep_need > 0 ? keep : nullptr, st))
+            return e;
         slots_used = (int)(rows / g->n);
     } else {
     GN_HIP(hipMemsetAsync(a, 0, 3 * slab * sizeof(float), st));

@@ -48,6 +48,8 @@ __device__ __forceinline__ void gather2_row_lds(const int* __restrict__ col, con
 }
 
 // One workgroup = nt x 256 threads (nt = ceil(n/32) <= 2): row tile t is served by waves 4t .. 4t+3.
+// KEEP: the forward's kept activations are read back (a compile-time switch: the recomputing instance stays as it was)
+template <bool KEEP>
 __global__ __launch_bounds__(512) void k_tiny_bwd64(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                     long rows, const float* __restrict__ sol, const float* __restrict__ x,
                                                     const float* __restrict__ gS, const float* __restrict__ gI,
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(512) void k_tiny_bwd64(const int* __restrict__ rowp
                                                     const float* __restrict__ bias, const float* __restrict__ w3,
                                                     const float* __restrict__ b3, const float* __restrict__ w2,
                                                     const float* __restrict__ b2, TinyBwdSched sched,
-                                                    float* __restrict__ part_all) {
+                                                    float* __restrict__ part_all, const float* __restrict__ keep) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const PartLayout L{64};
     const int nt = (n + TILE_ROWS - 1) / TILE_ROWS, tile_f = TILE_ROWS * TS;
@@ -110,15 +112,21 @@ __global__ __launch_bounds__(512) void k_tiny_bwd64(const int* __restrict__ rowp
 
     // Rows of sol at one grid point: y_i feeds the interval's MFMAs AND (one interval earlier in the sweep) the head's
     // VJP at that grid point, so each row is fetched once, one interval ahead of its first use.
-    struct GridRows { float4 y[2][3]; float gout[2][3]; };
+    // With the forward's kept activations (gn_keep_zs / gn_keep_zi: grid points 0 .. n_steps-1) the rows' Z_S(y_i), Z_I(y_i)
+    // ride along with the y rows instead of being recomputed: one matrix phase and one barrier less per interval -- the
+    // sweep is a chain of matrix phases on ONE CU, so that is where its time goes.
+    struct GridRows { float4 y[2][3]; float gout[2][3]; float4 zs[2], zi[2]; };
     auto fetch = [&](int gi, GridRows& r) {
         const int s = sched.slot[gi];
         const float* Yg = sol + (size_t)gi * 4 * slab;
+        const bool kept = KEEP && gi >= 1 && gi < sched.n_steps;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             r.y[p][0] = r.y[p][1] = r.y[p][2] = zero4();
             r.gout[p][0] = r.gout[p][1] = r.gout[p][2] = 0.f;
+            r.zs[p] = r.zi[p] = zero4();
             if (!valid[p]) continue;
+            if (kept) { r.zs[p] = ld4g(gn_keep_zs(keep, rows, gi) + off[p]); r.zi[p] = ld4g(gn_keep_zi(keep, rows, gi) + off[p]); }
             r.y[p][0] = ld4g(Yg + off[p]); r.y[p][1] = ld4g(Yg + slab + off[p]);
             if (s >= 0) {
                 r.y[p][2] = ld4g(Yg + 2 * slab + off[p]);
@@ -155,23 +163,33 @@ __global__ __launch_bounds__(512) void k_tiny_bwd64(const int* __restrict__ rowp
     for (int i = sched.n_steps; i >= 1; --i) {
         const float dt = sched.dt[i - 1];
         // 1. y_i rows of this tile (fetched one interval ago); start fetching grid point i-1
+        const bool kept = KEEP && i < sched.n_steps;                // uniform: the forward evaluated the RHS at y_i and kept Z
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             *reinterpret_cast<float4*>(Yt0 + lr[p] * TS + 4 * sub) = cur.y[p][0];
             *reinterpret_cast<float4*>(Yt1 + lr[p] * TS + 4 * sub) = cur.y[p][1];
+            // (own rows only: nobody else touches them between the previous interval's last barrier and the next one)
+            if (kept) *reinterpret_cast<float4*>(ZIm + lr[p] * TS + 4 * sub) = cur.zi[p];
         }
-        fetch(i - 1, nxt);
-        __syncthreads();
-        // 2. Z_S (into Dt0 for now) and Z_I (straight into the gather table)
-        if (blk2) { mfma_tile<true>(Yt0, Wl, Dt0, bias_l, w, lane); mfma_tile<true>(Yt1, Wl, ZIm, bias_l, w, lane); }
-        else { mfma_tile16<true>(Yt0, Wl, Dt0, bias_l, w, lane); mfma_tile16<true>(Yt1, Wl, ZIm, bias_l, w, lane); }
-        __syncthreads();
-        // 3. q = beta (a_I - a_S) Z_S
         float4 zs[2], zi[2];
 #pragma unroll
+        for (int p = 0; p < 2; ++p) { zs[p] = cur.zs[p]; zi[p] = cur.zi[p]; }
+        fetch(i - 1, nxt);
+        if (!kept) {
+            __syncthreads();
+            // 2. Z_S (into Dt0 for now) and Z_I (straight into the gather table)
+            if (blk2) { mfma_tile<true>(Yt0, Wl, Dt0, bias_l, w, lane); mfma_tile<true>(Yt1, Wl, ZIm, bias_l, w, lane); }
+            else { mfma_tile16<true>(Yt0, Wl, Dt0, bias_l, w, lane); mfma_tile16<true>(Yt1, Wl, ZIm, bias_l, w, lane); }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                zs[p] = *reinterpret_cast<const float4*>(Dt0 + lr[p] * TS + 4 * sub);
+                zi[p] = *reinterpret_cast<const float4*>(ZIm + lr[p] * TS + 4 * sub);
+            }
+        }
+        // 3. q = beta (a_I - a_S) Z_S
+#pragma unroll
         for (int p = 0; p < 2; ++p) {
-            zs[p] = *reinterpret_cast<const float4*>(Dt0 + lr[p] * TS + 4 * sub);
-            zi[p] = *reinterpret_cast<const float4*>(ZIm + lr[p] * TS + 4 * sub);
             *reinterpret_cast<float4*>(Qm + lr[p] * TS + 4 * sub) =
                 make_float4(bt[p] * (aI[p].x - aS[p].x) * zs[p].x, bt[p] * (aI[p].y - aS[p].y) * zs[p].y,
                             bt[p] * (aI[p].z - aS[p].z) * zs[p].z, bt[p] * (aI[p].w - aS[p].w) * zs[p].w);
@@ -310,13 +328,14 @@ bool gn_tiny_bwd64_ok(const gnode_graph_s* g, long rows, int H, int n_steps) {
 }
 
 int gn_bwd_tiny_set_attributes() {      // once per device, from gnode_graph_create
-    GN_HIP(hipFuncSetAttribute((const void*)k_tiny_bwd64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GN_HIP(hipFuncSetAttribute((const void*)k_tiny_bwd64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GN_HIP(hipFuncSetAttribute((const void*)k_tiny_bwd64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return 0;
 }
 
 int gn_launch_tiny_bwd64(const gnode_graph_s* g, long rows, const float* x, const gnode_params* p, const float* dt_host,
                          int n_steps, const int32_t* out_rows_host, int n_out, const float* sol, const float* gS,
-                         const float* gI, const float* gR, float* part, hipStream_t st) {
+                         const float* gI, const float* gR, float* part, const float* keep, hipStream_t st) {
     TinyBwdSched sched;
     sched.n_steps = n_steps;
     for (int k = 0; k < n_steps; ++k) sched.dt[k] = dt_host[k];
@@ -327,9 +346,10 @@ int gn_launch_tiny_bwd64(const gnode_graph_s* g, long rows, const float* x, cons
     }
     const unsigned B = (unsigned)(rows / g->n);
     const unsigned threads = 256u * (unsigned)((g->n + TILE_ROWS - 1) / TILE_ROWS);
-    hipLaunchKernelGGL(k_tiny_bwd64, dim3(B), dim3(threads), tiny_bwd_lds_bytes(g->n), st, g->rowptr, g->col, g->n, rows, sol, x,
+    auto kern = keep ? k_tiny_bwd64<true> : k_tiny_bwd64<false>;
+    hipLaunchKernelGGL(kern, dim3(B), dim3(threads), tiny_bwd_lds_bytes(g->n), st, g->rowptr, g->col, g->n, rows, sol, x,
                        gS, gI, gR, p->odefunc_linear_weight, p->odefunc_linear_bias, p->linear3_weight, p->linear3_bias,
-                       p->linearS2_weight, p->linearS2_bias, sched, part);
+                       p->linearS2_weight, p->linearS2_bias, sched, part, keep);
     GN_LAUNCH_CHECK();
     return 0;
 }

@@ -45,10 +45,10 @@ int gn_sir_set_attributes();
 // Z_S(y_k) and Z_I(y_k).  Z_I(y_k) IS step k's gather table (the row behind it is the table's zero row), so keeping it costs
 // the forward nothing; Z_S(y_k) is one more streamed slab per step.  The adjoint backward reads them back instead of
 // recomputing three 64x64 products and 3 x 64 sigmoids per row and interval (it is FP32-issue bound, not byte bound).
-static inline size_t gn_keep_stride(long rows) { return ((size_t)rows + 1) * 64; }
+__host__ __device__ static inline size_t gn_keep_stride(long rows) { return ((size_t)rows + 1) * 64; }
 static inline size_t gn_keep_floats(long rows, int n_steps) { return (size_t)2 * (n_steps + 1) * gn_keep_stride(rows); }
-template <class T> static inline T* gn_keep_zs(T* keep, long rows, int k) { return keep + (size_t)(2 * k) * gn_keep_stride(rows); }
-template <class T> static inline T* gn_keep_zi(T* keep, long rows, int k) { return keep + (size_t)(2 * k + 1) * gn_keep_stride(rows); }
+template <class T> __host__ __device__ static inline T* gn_keep_zs(T* keep, long rows, int k) { return keep + (size_t)(2 * k) * gn_keep_stride(rows); }
+template <class T> __host__ __device__ static inline T* gn_keep_zi(T* keep, long rows, int k) { return keep + (size_t)(2 * k + 1) * gn_keep_stride(rows); }
 
 void gnode_set_error(const char* fmt, ...);
 

@@ -25,7 +25,8 @@ int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, flo
 bool gn_tiny64_ok(int n, int n_steps, int n_out, bool prj);
 int gn_launch_tiny64(const gnode_graph_s* g, long rows, const float* Y0, const float* ZI0, const float* PR0, const float* W,
                      const float* bias, const float* beta, const float* gamma, const float* dt_host, const int* slot_host,
-                     int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol, hipStream_t st);
+                     int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol,
+                     float* keep /* kept activations (gn_keep_zs / gn_keep_zi of grid points 0 .. n_steps-1), or null */, hipStream_t st);
 
 // encoder + beta/gamma + trajectory point 0 + read-out at grid point 0 + projected R + Z_I(y_0) in one launch
 // ZI / ZI_alt: the two gather tables, each [rows + 1][64]: row `rows` is the table's ZERO ROW (written here)

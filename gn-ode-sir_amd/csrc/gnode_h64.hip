@@ -467,7 +467,7 @@ __global__ __launch_bounds__(768) void k_tiny64(const int* __restrict__ rowptr, 
                                                 const float* __restrict__ w3, const float* __restrict__ b3,
                                                 const float* __restrict__ w2, const float* __restrict__ b2,
                                                 float* __restrict__ So, float* __restrict__ Io, float* __restrict__ Ro,
-                                                float* __restrict__ sol) {
+                                                float* __restrict__ sol, float* __restrict__ keep) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nt = (n + TILE_ROWS - 1) / TILE_ROWS, tile_f = TILE_ROWS * TS;
     float* Wl = lds;
@@ -562,6 +562,9 @@ __global__ __launch_bounds__(768) void k_tiny64(const int* __restrict__ rowptr, 
             if (solk && valid[p]) {
                 const size_t off = (size_t)(base + lrow[p]) * 64 + 4 * sub;
                 st4g(solk + off, ys[p]); st4g(solk + slab + off, yi[p]); st4g(solk + 2 * slab + off, yr[p]);
+                if (!PRJ && keep) {                // kept activations of grid point k (gn_keep_zs / gn_keep_zi): the adjoint sweep reads them back
+                    st4g(gn_keep_zs(keep, rows, k) + off, zs); st4g(gn_keep_zi(keep, rows, k) + off, zi);
+                }
             }
             if (slot >= 0) {
                 float pS, pI, pR;
@@ -595,7 +598,7 @@ bool gn_tiny64_ok(int n, int n_steps, int n_out, bool prj) {
 
 int gn_launch_tiny64(const gnode_graph_s* g, long rows, const float* Y0, const float* ZI0, const float* PR0, const float* W,
                      const float* bias, const float* beta, const float* gamma, const float* dt_host, const int* slot_host,
-                     int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol, hipStream_t st) {
+                     int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol, float* keep, hipStream_t st) {
     TinySched sched;
     sched.n_steps = n_steps;
     for (int k = 0; k < n_steps; ++k) { sched.dt[k] = dt_host[k]; sched.slot[k] = (short)slot_host[k]; }
@@ -605,10 +608,10 @@ int gn_launch_tiny64(const gnode_graph_s* g, long rows, const float* Y0, const f
     const unsigned threads = 256u * (unsigned)((g->n + TILE_ROWS - 1) / TILE_ROWS);
     if (prj) {
         hipLaunchKernelGGL(k_tiny64<true>, dim3(B), dim3(threads), lds, st, g->rowptr, g->col, g->n, rows, Y0, ZI0, PR0, W, bias, beta,
-                           gamma, sched, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, S, I, R, sol);
+                           gamma, sched, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, S, I, R, sol, keep);
     } else {
         hipLaunchKernelGGL(k_tiny64<false>, dim3(B), dim3(threads), lds, st, g->rowptr, g->col, g->n, rows, Y0, ZI0, PR0, W, bias, beta,
-                           gamma, sched, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, S, I, R, sol);
+                           gamma, sched, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, S, I, R, sol, keep);
     }
     GN_LAUNCH_CHECK();
     return 0;

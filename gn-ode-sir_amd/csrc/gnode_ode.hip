@@ -728,7 +728,7 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         int slots[128];
         for (int k = 0; k < n_steps; ++k) slots[k] = out_slot(k + 1);
         if (int e = gn_launch_tiny64(g, rows, Y, zi_cur, PR, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma,
-                                     dt_host, slots, n_steps, p, S, I, R, sol, st))
+                                     dt_host, slots, n_steps, p, S, I, R, sol, keep, st))
             return e;
         if (sol) {
             const size_t slab4 = slab / 4;
@@ -818,7 +818,8 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
 }
 
 extern "C" size_t gnode_forward_keep_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t n_steps, int32_t n_out) {
-    if (!g || rows <= 0 || !gn_sol_carries_ai(g, H, n_steps, n_out)) return 0;
+    (void)n_out;                                   // both H = 64 forms (tiled and one-launch) keep the same tables
+    if (!g || rows <= 0 || H != 64 || n_steps < 1) return 0;
     return gn_keep_floats((long)rows, n_steps) * sizeof(float);
 }
 

@@ -123,8 +123,8 @@ size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H, i
  * (see `sol` below), 0 when the 4th slab repeats beta, gamma at every grid point.  n_out: number of emitted grid
  * points (n_steps+1 when out_rows_host is NULL). */
 int gnode_sol_carries_neighbour_sums(gnode_graph_t g, int32_t H, int32_t n_steps, int32_t n_out);
-/* Size of the optional `keep` buffer of gnode_forward_f32 / gnode_backward_f32 (method 0), or 0 when this graph / H /
- * grid takes a path that keeps nothing (then pass NULL).  2 * (n_steps + 1) * (rows + 1) * H floats on the H = 64 path. */
+/* Size of the optional `keep` buffer of gnode_forward_f32 / gnode_backward_f32 (method 0), or 0 when this H keeps
+ * nothing (then pass NULL).  2 * (n_steps + 1) * (rows + 1) * H floats at H = 64 (the tiled and the one-launch form). */
 size_t gnode_forward_keep_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t n_steps, int32_t n_out);
 int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
                       int32_t n_steps, int32_t method, const int32_t* out_rows_host, int32_t n_out,
