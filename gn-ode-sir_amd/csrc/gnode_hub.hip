@@ -53,26 +53,26 @@ __global__ __launch_bounds__(256) void k_hub_seg(const int* __restrict__ seg_lo,
     for (int e0 = lo; e0 < hi; e0 += LPR) {
         const int cnt = min(LPR, hi - e0);
         const int mine = (sub < cnt) ? col[e0 + sub] : 0;
-        for (int j = 0; j < cnt; j += 4) {
-            const int c0 = __shfl(mine, j, LPR), c1 = __shfl(mine, min(j + 1, LPR - 1), LPR);
-            const int c2 = __shfl(mine, min(j + 2, LPR - 1), LPR), c3 = __shfl(mine, min(j + 3, LPR - 1), LPR);
-            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 u0 = z, u1 = z, u2 = z, u3 = z, v0 = z, v1 = z, v2 = z, v3 = z;
-            if (active) {
-                u0 = hld4(t0 + (size_t)c0 * H + 4 * sub);
-                if (j + 1 < cnt) u1 = hld4(t0 + (size_t)c1 * H + 4 * sub);
-                if (j + 2 < cnt) u2 = hld4(t0 + (size_t)c2 * H + 4 * sub);
-                if (j + 3 < cnt) u3 = hld4(t0 + (size_t)c3 * H + 4 * sub);
-                if (t1) {
-                    v0 = hld4(t1 + (size_t)c0 * H + 4 * sub);
-                    if (j + 1 < cnt) v1 = hld4(t1 + (size_t)c1 * H + 4 * sub);
-                    if (j + 2 < cnt) v2 = hld4(t1 + (size_t)c2 * H + 4 * sub);
-                    if (j + 3 < cnt) v3 = hld4(t1 + (size_t)c3 * H + 4 * sub);
+        // 8 neighbour rows (per table) in flight per lane group, summed in ascending column order
+        for (int j = 0; j < cnt; j += 8) {
+            int c[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) c[q] = __shfl(mine, min(j + q, LPR - 1), LPR);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 u[8], v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                u[q] = z; v[q] = z;
+                if (active && j + q < cnt) {
+                    u[q] = hld4(t0 + (size_t)c[q] * H + 4 * sub);
+                    if (t1) v[q] = hld4(t1 + (size_t)c[q] * H + 4 * sub);
                 }
             }
 #define HUB_ACC(A, V) A.x += V.x; A.y += V.y; A.z += V.z; A.w += V.w;
-            HUB_ACC(a0, u0) HUB_ACC(a0, u1) HUB_ACC(a0, u2) HUB_ACC(a0, u3)
-            HUB_ACC(a1, v0) HUB_ACC(a1, v1) HUB_ACC(a1, v2) HUB_ACC(a1, v3)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { HUB_ACC(a0, u[q]) }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { HUB_ACC(a1, v[q]) }
         }
     }
     if (!active) return;
@@ -95,6 +95,36 @@ __global__ __launch_bounds__(256) void k_hub_reduce(const int* __restrict__ hub_
     const float* p0 = P0 + ((size_t)b * n_seg) * H + 4 * sub;
     const float* p1 = P1 ? P1 + ((size_t)b * n_seg) * H + 4 * sub : nullptr;
     int s = s0;
+    // the largest hub sets this launch's duration (one lane group walks its segments): 32 partial rows in flight,
+    // summed in the same segment order as the 4-wide loop below (bit-identical results)
+    for (; s + 32 <= s1; s += 32) {
+        float4 u[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) u[q] = hld4(p0 + (size_t)(s + q) * H);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) { HUB_ACC(a0, u[q]) }
+        if (p1) {
+            float4 v[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) v[q] = hld4(p1 + (size_t)(s + q) * H);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) { HUB_ACC(a1, v[q]) }
+        }
+    }
+    for (; s + 16 <= s1; s += 16) {
+        float4 u[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) u[q] = hld4(p0 + (size_t)(s + q) * H);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { HUB_ACC(a0, u[q]) }
+        if (p1) {
+            float4 v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = hld4(p1 + (size_t)(s + q) * H);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { HUB_ACC(a1, v[q]) }
+        }
+    }
     for (; s + 4 <= s1; s += 4) {
         const float4 u0 = hld4(p0 + (size_t)s * H), u1 = hld4(p0 + (size_t)(s + 1) * H);
         const float4 u2 = hld4(p0 + (size_t)(s + 2) * H), u3 = hld4(p0 + (size_t)(s + 3) * H);
