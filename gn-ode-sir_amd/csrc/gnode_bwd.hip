@@ -610,7 +610,8 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_fused64(const int* __restrict_
 #ifndef GN_BWD_KEPT_HEAD_OCC
 #define GN_BWD_KEPT_HEAD_OCC 2
 #endif
-template <int OCC, bool HEAD>
+// HUBS: the graph has rows longer than the hub threshold (compile-time, so graphs without them carry none of that code)
+template <int OCC, bool HEAD, bool HUBS>
 __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__ rowhdr, const int* __restrict__ col, int n, long rows,
                                                     int tiles_per_sample, long total_tiles, const float* __restrict__ Qc,
                                                     float* __restrict__ Qn, const float* __restrict__ Ysol,
@@ -623,7 +624,8 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__
                                                     const float* __restrict__ gR, const float* __restrict__ w3,
                                                     const float* __restrict__ b3, const float* __restrict__ w2,
                                                     const float* __restrict__ b2, const int* __restrict__ hubidx,
-                                                    const float* __restrict__ GQhub, int n_hub, int do_next) {
+                                                    const float* __restrict__ HubP /* per-segment partial sums of A q at the hub rows, [B][n_seg][64] */,
+                                                    const int* __restrict__ hub_seg_ptr, int n_seg, int do_next) {
     __shared__ __attribute__((aligned(16))) float Wl[64 * TS];
     __shared__ __attribute__((aligned(16))) float tiles[6][16 * TS];
     float (*Dt)[16 * TS] = &tiles[0];              // Dt[0..1]: dpre_S, dpre_I
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__
     // Loads inside a tile are UNCONDITIONAL (no per-row branches: the register allocator loses the rolling gather
     // registers across them): padding rows read row 0 and are masked where it matters, absent neighbours read the q
     // table's ZERO ROW (row `rows`, kept zero by the host).
-    struct Row { bool valid, hub; int start, end, cnt; unsigned row, rowbase, mine, hoff; };
+    struct Row { bool valid, hub; int start, end, cnt, hcnt; unsigned row, rowbase, mine, hoff; };
     const unsigned zoff = (unsigned)rows * 256u;
     auto head_of = [&](int t, Row& r) {
         const int bq = t / tiles_per_sample;
@@ -673,11 +675,14 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__
         const int* h = rowhdr + (size_t)nodec * 20;
         r.start = h[0]; r.end = r.valid ? h[1] : r.start;
         const int c0 = h[4 + sub];
-        r.hub = false; r.hoff = 0u;
-        if (hubidx) {                                               // uniform
+        r.hub = false; r.hoff = 0u; r.hcnt = 0;
+        if (HUBS) {
             const int hb = hubidx[nodec];
             r.hub = r.valid && hb >= 0;
-            r.hoff = r.hub ? (unsigned)(bq * n_hub + hb) * 256u : 0u;
+            // a hub row's sum arrives as per-segment partials (k_hub_seg): rows [hoff, hoff + hcnt) of HubP
+            const int s0 = r.hub ? hub_seg_ptr[hb] : 0, s1 = r.hub ? hub_seg_ptr[hb + 1] : 0;
+            r.hoff = (unsigned)(bq * n_seg + s0) * 256u;
+            r.hcnt = s1 - s0;
         }
         r.cnt = r.hub ? 0 : r.end - r.start;
         r.mine = (sub < r.cnt) ? (r.rowbase + (unsigned)c0) * 256u : zoff;
@@ -704,9 +709,22 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__
         float4 aS = ld4so<NT>(aSp, off), aI = ld4so<NT>(aIp, off), aR = ld4so<NT>(aRp, off);
         const float4 zs = ld4so<NT>(ZSk, off), zi = ld4so<NT>(ZIk, off), ai = ld4so<NT>(AIk, off);
         float4 gq = zero4();
-        if (hubidx) {                                  // uniform: hub rows arrive pre-summed (their gather reads zero rows)
-            const float4 hq = ld4o(GQhub, cur.hoff + lane_b);
-            if (cur.hub) gq = hq;
+        if (HUBS) {                                    // hub rows (their gather reads zero rows)
+            // segment partials added in segment order, 8 in flight: what a separate reduction launch used to do
+            const int hc = cur.hcnt;
+            if (__any(hc > 0)) {
+                float4 hs = zero4();
+                for (int sg = 0; __any(sg < hc); sg += 8) {
+#define GN_HP(Q, U) float4 U = zero4(); if (sg + (Q) < hc) U = ld4o(HubP, cur.hoff + (unsigned)(sg + (Q)) * 256u + lane_b);
+                    GN_HP(0, u0) GN_HP(1, u1) GN_HP(2, u2) GN_HP(3, u3) GN_HP(4, u4) GN_HP(5, u5) GN_HP(6, u6) GN_HP(7, u7)
+#undef GN_HP
+                    hs.x += u0.x; hs.y += u0.y; hs.z += u0.z; hs.w += u0.w;  hs.x += u1.x; hs.y += u1.y; hs.z += u1.z; hs.w += u1.w;
+                    hs.x += u2.x; hs.y += u2.y; hs.z += u2.z; hs.w += u2.w;  hs.x += u3.x; hs.y += u3.y; hs.z += u3.z; hs.w += u3.w;
+                    hs.x += u4.x; hs.y += u4.y; hs.z += u4.z; hs.w += u4.w;  hs.x += u5.x; hs.y += u5.y; hs.z += u5.z; hs.w += u5.w;
+                    hs.x += u6.x; hs.y += u6.y; hs.z += u6.z; hs.w += u6.w;  hs.x += u7.x; hs.y += u7.y; hs.z += u7.z; hs.w += u7.w;
+                }
+                if (cur.hub) gq = hs;
+            }
         }
         // finish the gather: neighbours 0..7 are in flight since the previous tile; ascending column order throughout
         GN_ACC8
@@ -1211,15 +1229,20 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
             const int cur = (G - 1 - i) & 1;
             const bool two = !ai_saved || i == G - 1;          // A Z_I(y_{G-1}) was never needed by the forward
             const float *AIhub = nullptr, *GQhub = nullptr;
+            const bool kept_launch = keep && !two && rows < (1L << 24);
+            const float* HubP = nullptr;               // kept kernel: segment partials only, it adds them up itself
             if (two) { if (int e = gn_hub_gather(g, rows / g->n, 64, ZIb[cur], Qb[cur], hub_scratch, &AIhub, &GQhub, st)) return e; }
+            else if (kept_launch) { if (int e = gn_hub_segments(g, rows / g->n, 64, Qb[cur], hub_scratch, &HubP, st)) return e; }
             else if (int e = gn_hub_gather(g, rows / g->n, 64, Qb[cur], nullptr, hub_scratch, &GQhub, nullptr, st)) return e;
             const int s = slot_of(i - 1);
             const float* gSs = s >= 0 ? gS + (size_t)s * rows : nullptr;
             const bool sampled = gn_prof_begin(2, st);
-            if (keep && !two && rows < (1L << 24)) {
+            if (kept_launch) {
                 // the head instance carries 25 more accumulators and the head's temporaries: two workgroups per CU there
                 constexpr int HOCC = GN_BWD_KEPT_HEAD_OCC;
-                auto kept_kernel = gSs ? k_bwd_kept64<HOCC, true> : k_bwd_kept64<GN_BWD_RPG1_OCC, false>;
+                const bool hubs = g->n_hub > 0;
+                auto kept_kernel = gSs ? (hubs ? k_bwd_kept64<HOCC, true, true> : k_bwd_kept64<HOCC, true, false>)
+                                       : (hubs ? k_bwd_kept64<GN_BWD_RPG1_OCC, false, true> : k_bwd_kept64<GN_BWD_RPG1_OCC, false, false>);
                 const int kgrid = gSs ? (int)std::min<long>((long)HOCC * g->num_cu, grid) : grid;
                 hipLaunchKernelGGL(kept_kernel, dim3(kgrid), dim3(256), 0, st, g->rowhdr, g->col, g->n, (long)rows,
                                    tps, total, Qb[cur], Qb[cur ^ 1], sol + (size_t)i * 4 * slab, sol + (size_t)(i - 1) * 4 * slab,
@@ -1227,7 +1250,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                                    sol + (size_t)i * 4 * slab + 3 * slab, p->odefunc_linear_weight, beta, gamma, dt_host[i - 1],
                                    a, part, gSs, s >= 0 ? gI + (size_t)s * rows : nullptr,
                                    s >= 0 ? gR + (size_t)s * rows : nullptr, p->linear3_weight, p->linear3_bias,
-                                   p->linearS2_weight, p->linearS2_bias, g->hubidx, GQhub, g->n_hub, i > 1 ? 1 : 0);
+                                   p->linearS2_weight, p->linearS2_bias, g->hubidx, HubP, g->hub_seg_ptr, g->n_seg, i > 1 ? 1 : 0);
             } else {
             auto fused_kernel = two ? k_bwd_fused64<GN_BWD_RPG1_OCC, 1, true> : k_bwd_fused64<GN_BWD_RPG1_OCC, 1, false>;
             hipLaunchKernelGGL(fused_kernel, dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->n, (long)rows, tps, total,

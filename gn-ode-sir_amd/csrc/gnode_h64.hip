@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
                                                  const float* __restrict__ w3, const float* __restrict__ b3,
                                                  const float* __restrict__ w2, const float* __restrict__ b2,
                                                  float* __restrict__ PR, Step64Out out,
-                                                 const int* __restrict__ hubidx, const float* __restrict__ AIhub, int n_hub) {
+                                                 const int* __restrict__ hubidx, const float* __restrict__ HubP /* per-segment partial sums [B][n_seg][64] */,
+                                                 const int* __restrict__ hub_seg_ptr, int n_seg) {
     // out.ai (training): the neighbour sums A Z_I(y_k) of this step are kept for the adjoint backward, which then reads a
     // row back instead of gathering the table a second time
     // measured on the 75k-node benchmark and fixed: non-temporal streaming state accesses (the gather table keeps the
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
     int tile_it = t_it - b_it * tiles_per_sample;
 
     // ---- per-stage state.  Uniform across the workgroup: *_ok (tile inside the queue).  Per lane group: the row.
-    struct Stage { bool ok; bool valid; bool hub; unsigned row, base; int start, end; unsigned mine, mine2, hoff; };
+    struct Stage { bool ok; bool valid; bool hub; unsigned row, base; int start, end; unsigned mine, mine2, hoff; int hcnt; };
     const unsigned zoff = (unsigned)rows * 256u;           // byte offset of the table's zero row (one past the last row)
     auto fetch_head = [&](Stage& s) {                      // top of the chain: row id, row header, hub index
         s.ok = t_it < q_hi;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
         s.valid = s.ok && node < n;
         const int nodec = s.valid ? node : 0;
         s.row = s.valid ? (unsigned)b_it * (unsigned)n + (unsigned)node : 0u;
-        s.start = 0; s.end = 0; s.hub = false; s.mine = zoff; s.hoff = 0u;
+        s.start = 0; s.end = 0; s.hub = false; s.mine = zoff; s.hoff = 0u; s.hcnt = 0;
         int c0 = 0;
         if (s.ok) {                                        // uniform: past the end of the queue nothing is requested at all
             // the row's header: extent and first 16 neighbour ids in one round trip (inside a tile the loads are
@@ -234,7 +235,10 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
             if (hubidx) {                                  // uniform: graphs without long rows skip all of this
                 const int h = hubidx[nodec];
                 s.hub = s.valid && h >= 0;
-                s.hoff = s.hub ? ((unsigned)b_it * (unsigned)n_hub + (unsigned)h) * 256u : 0u;
+                // a hub row's neighbour sum arrives as per-segment partials (k_hub_seg): [hoff, hoff + hcnt rows) of HubP
+                const int s0 = s.hub ? hub_seg_ptr[h] : 0, s1 = s.hub ? hub_seg_ptr[h + 1] : 0;
+                s.hoff = ((unsigned)b_it * (unsigned)n_seg + (unsigned)s0) * 256u;
+                s.hcnt = s1 - s0;
             }
         }
         if (!s.valid) s.end = s.start;
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
     };
 
     Stage cur, n1, n2;
-    cur.ok = false; cur.valid = false; cur.hub = false; cur.row = 0; cur.start = cur.end = 0; cur.mine = cur.mine2 = zoff; cur.hoff = 0; cur.base = 0;
+    cur.ok = false; cur.valid = false; cur.hub = false; cur.row = 0; cur.start = cur.end = 0; cur.mine = cur.mine2 = zoff; cur.hoff = 0; cur.hcnt = 0; cur.base = 0;
     fetch_head(n1);
     float4 ys_n1 = zero4();
     if (n1.ok) ys_n1 = ld4so<NT>(YS, n1.row * 256u + lane_b);
@@ -394,9 +398,23 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
                 v8 = gat_ld<8>(ZI, m, lane_b); v9 = gat_ld<9>(ZI, m, lane_b); v10 = gat_ld<10>(ZI, m, lane_b); v11 = gat_ld<11>(ZI, m, lane_b);
                 v12 = gat_ld<12>(ZI, m, lane_b); v13 = gat_ld<13>(ZI, m, lane_b); v14 = gat_ld<14>(ZI, m, lane_b); v15 = gat_ld<15>(ZI, m, lane_b);
             }
-            if (hubidx) {                                              // hub rows: the whole sum arrives pre-reduced
-                const float4 h = ld4o(AIhub, n1.hoff + lane_b);
-                if (n1.hub) v0 = h;
+            if (hubidx) {                                              // uniform: the graph has hub rows
+                // a hub row's sum = its segment partials added in segment order (what a separate reduction launch used to
+                // do: at mid size a launch costs as much as the step): 8 partial rows in flight, waves without a hub row skip
+                const int hc = n1.hcnt;
+                if (__any(hc > 0)) {
+                    float4 hs = zero4();
+                    for (int sg = 0; __any(sg < hc); sg += 8) {
+#define GN_HP(Q, U) float4 U = zero4(); if (sg + (Q) < hc) U = ld4o(HubP, n1.hoff + (unsigned)(sg + (Q)) * 256u + lane_b);
+                        GN_HP(0, u0) GN_HP(1, u1) GN_HP(2, u2) GN_HP(3, u3) GN_HP(4, u4) GN_HP(5, u5) GN_HP(6, u6) GN_HP(7, u7)
+#undef GN_HP
+                        hs.x += u0.x; hs.y += u0.y; hs.z += u0.z; hs.w += u0.w;  hs.x += u1.x; hs.y += u1.y; hs.z += u1.z; hs.w += u1.w;
+                        hs.x += u2.x; hs.y += u2.y; hs.z += u2.z; hs.w += u2.w;  hs.x += u3.x; hs.y += u3.y; hs.z += u3.z; hs.w += u3.w;
+                        hs.x += u4.x; hs.y += u4.y; hs.z += u4.z; hs.w += u4.w;  hs.x += u5.x; hs.y += u5.y; hs.z += u5.z; hs.w += u5.w;
+                        hs.x += u6.x; hs.y += u6.y; hs.z += u6.z; hs.w += u6.w;  hs.x += u7.x; hs.y += u7.y; hs.z += u7.z; hs.w += u7.w;
+                    }
+                    if (n1.hub) v0 = hs;
+                }
             }
             const unsigned off = n1.row * 256u + lane_b;
             yi = ld4so<NT>(YI, off);
@@ -730,8 +748,8 @@ int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, flo
                  "(split the batch)", rows);
     const int tps = (g->n + 15) / 16;
     const long total = (long)(rows / g->n) * tps;
-    const float* AIhub = nullptr;
-    if (int e = gn_hub_gather(g, rows / g->n, 64, ZI, nullptr, hub_scratch, &AIhub, nullptr, st)) return e;
+    const float* HubP = nullptr;               // per-segment partial sums of the hub rows; the step kernel adds them up itself
+    if (int e = gn_hub_segments(g, rows / g->n, 64, ZI, hub_scratch, &HubP, st)) return e;
     // persistent grid: GN_STEP_OCC workgroups per CU (measured: 3 / 4 / 5 per CU -> 363 / 360 / 400 us per launch on the
     // 75k graph x 8; shrinking the grid so that every workgroup gets the same number of tiles is slower than filling
     // every slot and accepting a +-1 tile imbalance)
@@ -739,7 +757,7 @@ int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, flo
     const bool lat = total <= grid;            // one tile per workgroup: the latency-mode instantiation
 #define GN_STEP(P, L) hipLaunchKernelGGL((k_step64<P, L>), dim3(grid), dim3(256), 0, st, g->rowhdr, g->col, g->n, rows, tps, total, Y, ZI, \
                                          ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,     \
-                                         p->linearS2_bias, PR, out, g->hubidx, AIhub, g->n_hub)
+                                         p->linearS2_bias, PR, out, g->hubidx, HubP, g->hub_seg_ptr, g->n_seg)
     if (PR) { if (lat) GN_STEP(true, true); else GN_STEP(true, false); }
     else { if (lat) GN_STEP(false, true); else GN_STEP(false, false); }
 #undef GN_STEP

@@ -207,6 +207,21 @@ size_t gn_hub_scratch_bytes(const gnode_graph_s* g, long B, int H, int ntables) 
     return (size_t)ntables * (gn_align(sizeof(float) * part_f) + gn_align(sizeof(float) * hub_f));
 }
 
+// Segment partials only (one table): *P0 points at [B][n_seg][H] inside `scratch`; the consumer adds a hub's segments up in
+// order itself (the H = 64 step kernel), which saves the reduction launch.  Same scratch layout as gn_hub_gather.
+int gn_hub_segments(const gnode_graph_s* g, long B, int H, const float* T0, void* scratch, const float** P0out, hipStream_t st) {
+    *P0out = nullptr;
+    if (g->n_hub == 0) return 0;
+    GN_CHECK_ARG(scratch, "hub rows present but no hub scratch was carved from the workspace");
+    float* P0 = (float*)scratch;
+    const int lpr = hub_lpr(H), gpw = 256 / lpr;
+    HUB_DISPATCH(lpr, hipLaunchKernelGGL(k_hub_seg<LPR>, dim3((unsigned)((g->n_seg + gpw - 1) / gpw), (unsigned)B), dim3(256), 0, st,
+                                         g->seg_lo, g->seg_hi, g->col, g->n, g->n_seg, H, T0, nullptr, P0, nullptr));
+    GN_LAUNCH_CHECK();
+    *P0out = P0;
+    return 0;
+}
+
 // Hub sums of one or two tables [B*n][H] (T1 may be null).  On return *A0 / *A1 point at [B][n_hub][H]
 // buffers inside `scratch` (>= gn_hub_scratch_bytes(g, B, H, T1 ? 2 : 1) bytes of the caller's workspace).
 int gn_hub_gather(const gnode_graph_s* g, long B, int H, const float* T0, const float* T1, void* scratch, const float** A0,
