@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256) void k_step_generic(const int* __restrict__ ro
                                                       float dt, const float* __restrict__ w3, const float* __restrict__ b3,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
                                                       StepOut out, const int* __restrict__ hubidx,
-                                                      const float* __restrict__ AIhub, int n_hub) {
+                                                      const float* __restrict__ HubP /* hub rows: per-segment partial sums [B][n_seg][H] */,
+                                                      const int* __restrict__ hub_seg_ptr, int n_seg) {
     extern __shared__ float Wt[];                 // [H][H] transposed: Wt[k][j] = W[j][k]
     for (int idx = threadIdx.x; idx < H * H; idx += 256) Wt[(size_t)(idx % H) * H + idx / H] = W[idx];
     __syncthreads();
@@ -330,8 +331,20 @@ __global__ __launch_bounds__(256) void k_step_generic(const int* __restrict__ ro
     const float nb = -beta[r], gm = gamma[r];
     const int hub = hubidx ? hubidx[node] : -1;
     float4 ai;
-    if (hub >= 0) ai = active ? ld4(AIhub + ((size_t)blockIdx.y * n_hub + hub) * H + 4 * sub) : z0;
-    else ai = gather_row<LPR>(rowptr, col, ZI + (size_t)base * H, node, sub, active, H);
+    if (hub >= 0) {
+        // long rows: their 32-edge segments were summed by k_hub_seg; add the partials up in segment order (what a separate
+        // reduction launch used to do -- at this size a launch costs as much as the step), 8 in flight
+        ai = z0;
+        const float* pp = HubP + (size_t)blockIdx.y * n_seg * H + 4 * sub;
+        const int s1 = hub_seg_ptr[hub + 1];
+        for (int sg = hub_seg_ptr[hub]; sg < s1; sg += 8) {
+            float4 u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) u[q] = (active && sg + q < s1) ? ld4(pp + (size_t)(sg + q) * H) : z0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { ai.x += u[q].x; ai.y += u[q].y; ai.z += u[q].z; ai.w += u[q].w; }
+        }
+    } else ai = gather_row<LPR>(rowptr, col, ZI + (size_t)base * H, node, sub, active, H);
     const float4 zs = group_mlp<LPR>(yS, Wt, bias4, sub, active, H);
     float4 dS, dI, dR;
     dS.x = nb * (ai.x * zs.x); dS.y = nb * (ai.y * zs.y); dS.z = nb * (ai.z * zs.z); dS.w = nb * (ai.w * zs.w);
@@ -763,8 +776,8 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
             // two-launch branch below, whose node MLP runs on the matrix cores (a VALU mat-vec is 12x off the bound there)
             StepOut out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
                            slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next};
-            const float* AIhub = nullptr;
-            if (int e = gn_hub_gather(g, rows / g->n, H, zi_cur, nullptr, hub_scratch, &AIhub, nullptr, st)) return e;
+            const float* HubP = nullptr;          // segment partials of the hub rows; the step kernel adds them up itself
+            if (int e = gn_hub_segments(g, rows / g->n, H, zi_cur, hub_scratch, &HubP, st)) return e;
             dim3 grid((unsigned)((g->n + rpw - 1) / rpw), (unsigned)(rows / g->n));
             const size_t lds = (size_t)H * H * sizeof(float);
             const bool sampled = prof_begin(0, st);
@@ -772,7 +785,7 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
             DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_step_generic<LPR>, grid, dim3(256), lds, st, g->rowptr, g->col, g->n, (long)rows, H,
                                                  Ycur, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma,
                                                  dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, out,
-                                                 g->hubidx, AIhub, g->n_hub));
+                                                 g->hubidx, HubP, g->hub_seg_ptr, g->n_seg));
             if (sampled) prof_mark(0, st);
             GN_LAUNCH_CHECK();
             std::swap(zi_cur, zi_nxt);
