@@ -869,8 +869,9 @@ __global__ __launch_bounds__(256) void k_bwd_fused_generic(
     const float* __restrict__ bias, const float* __restrict__ beta, const float* __restrict__ gamma, float dt,
     float* __restrict__ a, float* __restrict__ part_all, const float* __restrict__ gS, const float* __restrict__ gI,
     const float* __restrict__ gR, const float* __restrict__ w3, const float* __restrict__ b3, const float* __restrict__ w2,
-    const float* __restrict__ b2, const int* __restrict__ hubidx, const float* __restrict__ AIhub,
-    const float* __restrict__ GQhub, int n_hub, int do_next) {
+    const float* __restrict__ b2, const int* __restrict__ hubidx,
+    const float* __restrict__ HubP0 /* hub rows: per-segment partial sums of A Z_I, [B][n_seg][H] */,
+    const float* __restrict__ HubP1 /* ... of A q */, const int* __restrict__ hub_seg_ptr, int n_seg, int do_next) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int G = 256 / LPR;
     const PartLayout L{H};
@@ -922,9 +923,22 @@ __global__ __launch_bounds__(256) void k_bwd_fused_generic(
         if (inrow) {
             const int hub = hubidx ? hubidx[node] : -1;
             if (hub >= 0) {
-                if (lane_ok) {
-                    ai = ld4b(AIhub + ((size_t)b * n_hub + hub) * H + 4 * sub);
-                    gq = ld4b(GQhub + ((size_t)b * n_hub + hub) * H + 4 * sub);
+                // the hub's segment partials, added in segment order (no separate reduction launch), 4 per table in flight
+                const size_t pb = (size_t)b * n_seg * H + 4 * sub;
+                const int s1 = hub_seg_ptr[hub + 1];
+                for (int sg = hub_seg_ptr[hub]; sg < s1; sg += 4) {
+                    float4 u[4], v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool on = lane_ok && sg + q < s1;
+                        u[q] = on ? ld4b(HubP0 + pb + (size_t)(sg + q) * H) : z4();
+                        v[q] = on ? ld4b(HubP1 + pb + (size_t)(sg + q) * H) : z4();
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ai.x += u[q].x; ai.y += u[q].y; ai.z += u[q].z; ai.w += u[q].w;
+                        gq.x += v[q].x; gq.y += v[q].y; gq.z += v[q].z; gq.w += v[q].w;
+                    }
                 }
             } else {
                 gn_gather2<(LPR <= 4 ? 8 : 4)>(col, rowptr[node], rowptr[node + 1], ZIc + (size_t)b * n * H, Qc + (size_t)b * n * H, H, sub, lane_ok, ai, gq);
@@ -1277,8 +1291,8 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         slots_used = std::max(slots_used, grid);
         for (int i = G - 1; i >= 1; --i) {
             const int cur = (G - 1 - i) & 1;
-            const float *AIhub = nullptr, *GQhub = nullptr;
-            if (int e = gn_hub_gather(g, rows / g->n, H, ZIb[cur], Qb[cur], hub_scratch, &AIhub, &GQhub, st)) return e;
+            const float *HubP0 = nullptr, *HubP1 = nullptr;        // segment partials; the interval kernel adds them up itself
+            if (int e = gn_hub_segments2(g, rows / g->n, H, ZIb[cur], Qb[cur], hub_scratch, &HubP0, &HubP1, st)) return e;
             const int s = slot_of(i - 1);
             BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_bwd_fused_generic<LPR>, dim3(grid), dim3(256), fl * sizeof(float), st, g->rowptr,
                                                  g->col, g->n, (long)rows, H, ZS, ZIb[cur], Qb[cur], ZIb[cur ^ 1], Qb[cur ^ 1],
@@ -1287,7 +1301,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                                                  part, s >= 0 ? gS + (size_t)s * rows : nullptr,
                                                  s >= 0 ? gI + (size_t)s * rows : nullptr, s >= 0 ? gR + (size_t)s * rows : nullptr,
                                                  p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias,
-                                                 g->hubidx, AIhub, GQhub, g->n_hub, i > 1 ? 1 : 0));
+                                                 g->hubidx, HubP0, HubP1, g->hub_seg_ptr, g->n_seg, i > 1 ? 1 : 0));
             GN_LAUNCH_CHECK();
         }
     } else

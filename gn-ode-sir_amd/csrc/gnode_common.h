@@ -33,6 +33,8 @@ size_t gn_hub_scratch_bytes(const gnode_graph_s* g, long B, int H, int ntables);
 int gn_hub_gather(const gnode_graph_s* g, long B, int H, const float* T0, const float* T1, void* scratch, const float** A0,
                   const float** A1, hipStream_t st);
 int gn_hub_segments(const gnode_graph_s* g, long B, int H, const float* T0, void* scratch, const float** P0, hipStream_t st);
+int gn_hub_segments2(const gnode_graph_s* g, long B, int H, const float* T0, const float* T1, void* scratch, const float** P0,
+                     const float** P1, hipStream_t st);
 
 // per-device one-time setup (dynamic-LDS attributes of every kernel that may need more than 64 KB), run by
 // gnode_graph_create for the current device; each translation unit contributes its kernels

@@ -210,15 +210,25 @@ size_t gn_hub_scratch_bytes(const gnode_graph_s* g, long B, int H, int ntables) 
 // Segment partials only (one table): *P0 points at [B][n_seg][H] inside `scratch`; the consumer adds a hub's segments up in
 // order itself (the H = 64 step kernel), which saves the reduction launch.  Same scratch layout as gn_hub_gather.
 int gn_hub_segments(const gnode_graph_s* g, long B, int H, const float* T0, void* scratch, const float** P0out, hipStream_t st) {
+    return gn_hub_segments2(g, B, H, T0, nullptr, scratch, P0out, nullptr, st);
+}
+
+// ... of one or two tables gathered through the same neighbour lists (T1 / P1out may be null)
+int gn_hub_segments2(const gnode_graph_s* g, long B, int H, const float* T0, const float* T1, void* scratch, const float** P0out,
+                     const float** P1out, hipStream_t st) {
     *P0out = nullptr;
+    if (P1out) *P1out = nullptr;
     if (g->n_hub == 0) return 0;
     GN_CHECK_ARG(scratch, "hub rows present but no hub scratch was carved from the workspace");
+    const size_t part_b = gn_align(sizeof(float) * (size_t)B * g->n_seg * H);
     float* P0 = (float*)scratch;
+    float* P1 = T1 ? (float*)((char*)scratch + part_b) : nullptr;       // (inside the two-table scratch of gn_hub_scratch_bytes)
     const int lpr = hub_lpr(H), gpw = 256 / lpr;
     HUB_DISPATCH(lpr, hipLaunchKernelGGL(k_hub_seg<LPR>, dim3((unsigned)((g->n_seg + gpw - 1) / gpw), (unsigned)B), dim3(256), 0, st,
-                                         g->seg_lo, g->seg_hi, g->col, g->n, g->n_seg, H, T0, nullptr, P0, nullptr));
+                                         g->seg_lo, g->seg_hi, g->col, g->n, g->n_seg, H, T0, T1, P0, P1));
     GN_LAUNCH_CHECK();
     *P0out = P0;
+    if (P1out) *P1out = P1;
     return 0;
 }
 
