@@ -12,9 +12,13 @@
 //                segments of <= 32 edges (uniform work items).
 //   k_hub_seg    one lane group per (sample, segment): partial[b][s][:] = sum of the segment's
 //                neighbour rows, ascending column order inside the segment.
-//   k_hub_reduce one lane group per (sample, hub): AIhub[b][h][:] = partials of the hub summed in
-//                segment order (contiguous, coalesced reads).
-//   consumers    step / derivative / backward kernels read AIhub for hub rows and gather the rest.
+//   consumers    the step kernels (H = 64 and generic H), the backward over kept activations and the H <= 32 interval
+//                kernel add a hub's partials up THEMSELVES, in segment order, several partial rows in flight
+//                (gn_hub_segments / gn_hub_segments2): a second launch per step cost 17-35 us on the 75k Chung-Lu
+//                graph and as much as the whole step at mid size.  They gather the other rows as usual.
+//   k_hub_reduce for the remaining consumers (RHS API, RK4 stages, the recomputing and five-launch backward forms):
+//                one lane group per (sample, hub): AIhub[b][h][:] = partials of the hub summed in the same
+//                segment order (gn_hub_gather); those kernels read AIhub for hub rows.
 //
 // Deterministic (no atomics): a hub's sum is blocked by segment but always in the same order.
 // Up to two tables are reduced through the same index lists in one pass (the backward needs
