@@ -57,15 +57,15 @@ __global__ __launch_bounds__(256) void k_hub_seg(const int* __restrict__ seg_lo,
     for (int e0 = lo; e0 < hi; e0 += LPR) {
         const int cnt = min(LPR, hi - e0);
         const int mine = (sub < cnt) ? col[e0 + sub] : 0;
-        // 8 neighbour rows (per table) in flight per lane group, summed in ascending column order
-        for (int j = 0; j < cnt; j += 8) {
-            int c[8];
+        // 16 neighbour rows (per table) in flight per lane group, summed in ascending column order
+        for (int j = 0; j < cnt; j += 16) {
+            int c[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) c[q] = __shfl(mine, min(j + q, LPR - 1), LPR);
+            for (int q = 0; q < 16; ++q) c[q] = __shfl(mine, min(j + q, LPR - 1), LPR);
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 u[8], v[8];
+            float4 u[16], v[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 16; ++q) {
                 u[q] = z; v[q] = z;
                 if (active && j + q < cnt) {
                     u[q] = hld4(t0 + (size_t)c[q] * H + 4 * sub);
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void k_hub_seg(const int* __restrict__ seg_lo,
             }
 #define HUB_ACC(A, V) A.x += V.x; A.y += V.y; A.z += V.z; A.w += V.w;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { HUB_ACC(a0, u[q]) }
+            for (int q = 0; q < 16; ++q) { HUB_ACC(a0, u[q]) }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { HUB_ACC(a1, v[q]) }
+            for (int q = 0; q < 16; ++q) { HUB_ACC(a1, v[q]) }
         }
     }
     if (!active) return;
