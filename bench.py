@@ -156,11 +156,11 @@ def bench_train(lib, dev, n, m, B, H, maxTime, deltaT, reps):
 def bwd_interval_bytes(n, nnz, H):
     """One sample, one interval of the adjoint kernel over kept activations (k_bwd_kept64): the A q
     gather plus the slab rows it reads and writes.  Reads a_S, a_I, a_R (3) + y_i S, I rows (2) + the forward's kept
-    Z_S(y_i), Z_I(y_i) (2) + kept A Z_I(y_i) (1) + kept Z_S(y_{i-1}) (1) + y_{i-1} S, I, R rows at output grid points
+    P_S(y_i) = A Z_I * Z_S (1 - Z_S) and Z_I(y_i) (2) + kept Z_S(y_{i-1}) (1) + y_{i-1} S, I, R rows at output grid points
     (every second interval with the fused subsample: 1.5 on average); writes a_S, a_I (2) + a_R at output points (0.5)
     + the next interval's q table (1)."""
     slab = n * H * 4
-    slabs = 3 + 2 + 2 + 1 + 1 + 1.5 + 2 + 0.5 + 1
+    slabs = 3 + 2 + 2 + 1 + 1.5 + 2 + 0.5 + 1
     csr = nnz * 4 + n * 20 * 4                  # column ids + row headers
     return {"algorithmic": csr + nnz * H * 4 + slabs * slab, "compulsory": csr + slabs * slab}
 

@@ -615,9 +615,9 @@ template <int OCC, bool HEAD, bool HUBS>
 __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__ rowhdr, const int* __restrict__ col, int n, long rows,
                                                     int tiles_per_sample, long total_tiles, const float* __restrict__ Qc,
                                                     float* __restrict__ Qn, const float* __restrict__ Ysol,
-                                                    const float* __restrict__ Yprev, const float* __restrict__ ZSk,
+                                                    const float* __restrict__ Yprev, const float* __restrict__ PSk /* kept P_S(y_i) */,
                                                     const float* __restrict__ ZIk, const float* __restrict__ ZSp,
-                                                    const float* __restrict__ AIk, const float* __restrict__ W,
+                                                    const float* __restrict__ W,
                                                     const float* __restrict__ beta, const float* __restrict__ gamma, float dt,
                                                     float* __restrict__ a, float* __restrict__ part_all,
                                                     const float* __restrict__ gS, const float* __restrict__ gI,
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__
         const unsigned off = cur.row * 256u + lane_b;
         const float bt = valid ? beta[cur.row] : 0.f, gm = gamma[cur.row];
         float4 aS = ld4so<NT>(aSp, off), aI = ld4so<NT>(aIp, off), aR = ld4so<NT>(aRp, off);
-        const float4 zs = ld4so<NT>(ZSk, off), zi = ld4so<NT>(ZIk, off), ai = ld4so<NT>(AIk, off);
+        const float4 ps = ld4so<NT>(PSk, off), zi = ld4so<NT>(ZIk, off);
         float4 gq = zero4();
         if (HUBS) {                                    // hub rows (their gather reads zero rows)
             // segment partials added in segment order, 8 in flight: what a separate reduction launch used to do
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256, OCC) void k_bwd_kept64(const int* __restrict__
 #define GN_DP(c)                                                               \
             {                                                                  \
                 const float v = bt * (aI.c - aS.c);                            \
-                dS.c = (v * ai.c) * (zs.c * (1.0f - zs.c));                    \
+                dS.c = v * ps.c;                                               \
                 dI.c = valid ? (gq.c + gm * (aR.c - aI.c)) * (zi.c * (1.0f - zi.c)) : 0.f;   \
             }
             GN_DP(x) GN_DP(y) GN_DP(z) GN_DP(w)
@@ -1260,8 +1260,8 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                 const int kgrid = gSs ? (int)std::min<long>((long)HOCC * g->num_cu, grid) : grid;
                 hipLaunchKernelGGL(kept_kernel, dim3(kgrid), dim3(256), 0, st, g->rowhdr, g->col, g->n, (long)rows,
                                    tps, total, Qb[cur], Qb[cur ^ 1], sol + (size_t)i * 4 * slab, sol + (size_t)(i - 1) * 4 * slab,
-                                   gn_keep_zs(keep, rows, i), gn_keep_zi(keep, rows, i), gn_keep_zs(keep, rows, i - 1),
-                                   sol + (size_t)i * 4 * slab + 3 * slab, p->odefunc_linear_weight, beta, gamma, dt_host[i - 1],
+                                   gn_keep_ps(keep, rows, i), gn_keep_zi(keep, rows, i), gn_keep_zs(keep, rows, i - 1),
+                                   p->odefunc_linear_weight, beta, gamma, dt_host[i - 1],
                                    a, part, gSs, s >= 0 ? gI + (size_t)s * rows : nullptr,
                                    s >= 0 ? gR + (size_t)s * rows : nullptr, p->linear3_weight, p->linear3_bias,
                                    p->linearS2_weight, p->linearS2_bias, g->hubidx, HubP, g->hub_seg_ptr, g->n_seg, i > 1 ? 1 : 0);

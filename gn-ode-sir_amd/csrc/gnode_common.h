@@ -44,14 +44,18 @@ int gn_bwd_set_attributes();
 int gn_bwd_tiny_set_attributes();
 int gn_sir_set_attributes();
 
-// The training forward's KEPT ACTIVATIONS (H = 64 fused path): per grid point k two tables of rows + 1 rows of 64 floats,
-// Z_S(y_k) and Z_I(y_k).  Z_I(y_k) IS step k's gather table (the row behind it is the table's zero row), so keeping it costs
-// the forward nothing; Z_S(y_k) is one more streamed slab per step.  The adjoint backward reads them back instead of
-// recomputing three 64x64 products and 3 x 64 sigmoids per row and interval (it is FP32-issue bound, not byte bound).
+// The training forward's KEPT ACTIVATIONS (H = 64): per grid point k three tables of rows + 1 rows of 64 floats --
+//   Z_S(y_k); Z_I(y_k); P_S(y_k) = (A Z_I(y_k)) * Z_S(y_k) * (1 - Z_S(y_k)).
+// Z_I(y_k) IS step k's gather table (the row behind it is the table's zero row), so keeping it costs the forward nothing;
+// Z_S and P_S are one streamed slab each per step (P_S takes the place of the A Z_I row a forward without `keep` parks in the
+// trajectory's 4th slab).  The adjoint backward reads them back instead of gathering a second table and recomputing three
+// 64x64 products and 192 sigmoids per row and interval; P_S is the ONLY form in which it needs A Z_I, so it reads one slab
+// row where A Z_I and Z_S(y_i) would be two.  The one-launch (tiny-graph) forms keep and use Z_S, Z_I only.
 __host__ __device__ static inline size_t gn_keep_stride(long rows) { return ((size_t)rows + 1) * 64; }
-static inline size_t gn_keep_floats(long rows, int n_steps) { return (size_t)2 * (n_steps + 1) * gn_keep_stride(rows); }
-template <class T> __host__ __device__ static inline T* gn_keep_zs(T* keep, long rows, int k) { return keep + (size_t)(2 * k) * gn_keep_stride(rows); }
-template <class T> __host__ __device__ static inline T* gn_keep_zi(T* keep, long rows, int k) { return keep + (size_t)(2 * k + 1) * gn_keep_stride(rows); }
+static inline size_t gn_keep_floats(long rows, int n_steps) { return (size_t)3 * (n_steps + 1) * gn_keep_stride(rows); }
+template <class T> __host__ __device__ static inline T* gn_keep_zs(T* keep, long rows, int k) { return keep + (size_t)(3 * k) * gn_keep_stride(rows); }
+template <class T> __host__ __device__ static inline T* gn_keep_zi(T* keep, long rows, int k) { return keep + (size_t)(3 * k + 1) * gn_keep_stride(rows); }
+template <class T> __host__ __device__ static inline T* gn_keep_ps(T* keep, long rows, int k) { return keep + (size_t)(3 * k + 2) * gn_keep_stride(rows); }
 
 void gnode_set_error(const char* fmt, ...);
 

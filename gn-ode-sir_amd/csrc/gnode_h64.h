@@ -5,7 +5,8 @@
 struct Step64Out {
     float* S; float* I; float* R;   // this step's output rows [rows], or null
     float* sol;                     // sol[g+1] base ([4*rows, 64]), or null
-    float* ai;                      // [rows, 64] receives this step's neighbour sums A Z_I(y_g) (kept for the backward), or null
+    float* ai;                      // [rows, 64] receives this step's neighbour sums A Z_I(y_g) -- times Z_S (1 - Z_S) when `zs` is
+                                    // given too (gn_keep_ps) -- kept for the backward, or null
     float* zs;                      // [rows, 64] receives Z_S(y_g) (kept for the backward, see gn_keep_zs), or null
 };
 

@@ -376,7 +376,12 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
             if (cur.valid) {
                 st4so<NT>(YSo, off, ys); st4so<NT>(YIo, off, yi);
                 if (!PRJ) st4so<NT>(YRo, off, yr);
-                if (!PRJ && out.ai) st4so<NT>(out.ai, off, acc);
+                if (!PRJ && out.ai) {
+                    // without `keep`: A Z_I(y_k) itself; with it: P_S = A Z_I * Z_S (1 - Z_S), the only form the backward needs
+                    if (out.zs) st4so<NT>(out.ai, off, make_float4(acc.x * (zs.x * (1.0f - zs.x)), acc.y * (zs.y * (1.0f - zs.y)),
+                                                                  acc.z * (zs.z * (1.0f - zs.z)), acc.w * (zs.w * (1.0f - zs.w))));
+                    else st4so<NT>(out.ai, off, acc);
+                }
                 if (!PRJ && out.zs) st4so<NT>(out.zs, off, zs);
             }
             if (out.S) {

@@ -762,7 +762,8 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
             // receives A Z_I(y_k), which the adjoint backward would otherwise gather again
             Step64Out out = {slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
                              slot >= 0 ? R + (size_t)slot * rows : nullptr, sol_next,
-                             (sol && k >= 1) ? sol + (size_t)k * 4 * slab + 3 * slab : nullptr,
+                             keep ? (k >= 1 ? gn_keep_ps(keep, rows, k) : nullptr)          // with `keep`: P_S(y_k) there instead
+                                  : ((sol && k >= 1) ? sol + (size_t)k * 4 * slab + 3 * slab : nullptr),
                              keep ? gn_keep_zs(keep, rows, k) : nullptr};
             const bool sampled = prof_begin(0, st);
             if (int e = gn_launch_step64(g, rows, Ycur, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,

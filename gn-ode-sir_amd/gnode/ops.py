@@ -134,6 +134,9 @@ def backward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarra
     p, gp = pack_params({k: v.detach() for k, v in params.items()}), pack_params(grads)
     if isinstance(keep, str):
         keep = getattr(sol, "gnode_keep", None)
+    elif keep is None and getattr(sol, "gnode_keep", None) is not None and H == 64:
+        # (a trajectory produced WITH kept activations does not carry A Z_I in its 4th slabs: include/gnode.h)
+        raise _lib.GnodeError("this trajectory was produced with a keep buffer: pass it (keep='auto'), or run the forward with want_keep=False")
     _lib.check(lib.gnode_backward_f32(
         graph.handle, _lib.ptr(x2d), C.byref(p), _lib.host_ptr(dts), n_steps,
         _lib.host_ptr(out_rows) if out_rows is not None else None, n_out, _lib.ptr(_f32c(sol)),

@@ -108,23 +108,29 @@ int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* 
  *              point) is odeint's at grid point 0 everywhere; at H = 64 (the fused
  *              path, graphs that do not fit the one-launch kernel) grid points
  *              1 .. n_steps-1 carry A*Z_I(y_k) there instead -- the neighbour sums
- *              the adjoint backward would otherwise gather a second time -- and the
- *              last grid point's is left unwritten; other H repeat beta, gamma.
+ *              the adjoint backward would otherwise gather a second time -- when no
+ *              `keep` buffer is given, and are left UNWRITTEN when one is (the sums then
+ *              live in `keep`, in the form the backward uses); the last grid point's is
+ *              always left unwritten; other H repeat beta, gamma.
  *   keep       NULL, or device buffer of keep_bytes >= gnode_forward_keep_bytes(...):
  *              the KEPT ACTIVATIONS sigmoid(W y_k + b) of the S and I compartments at
  *              every grid point, which the fused H = 64 path has in registers anyway
  *              and gnode_backward_f32 then reads back instead of recomputing (three
- *              of its seven 64x64 products per row and every sigmoid).  Opaque layout;
- *              ignored when sol is NULL or gnode_forward_keep_bytes() is 0.  Outputs
- *              and sol do not depend on whether keep is given.
+ *              of its seven 64x64 products per row and every sigmoid), plus, on the
+ *              tiled path, the neighbour sums A*Z_I(y_k) already multiplied by the
+ *              sigmoid's derivative.  Opaque layout; ignored when sol is NULL or
+ *              gnode_forward_keep_bytes() is 0.  Outputs and the S, I, R slabs of sol
+ *              do not depend on whether keep is given.  A trajectory and the keep buffer
+ *              of the same call belong together: hand gnode_backward_f32 both, or a
+ *              trajectory that was produced WITHOUT keep and NULL.
  *   workspace  device, >= gnode_forward_workspace_bytes(g, rows, H, method) */
 size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t method);
-/* 1 when gnode_forward_f32 (method 0) on this graph stores A*Z_I(y_k) in the 4th slab of sol[k], 1 <= k <= n_steps-1
- * (see `sol` below), 0 when the 4th slab repeats beta, gamma at every grid point.  n_out: number of emitted grid
- * points (n_steps+1 when out_rows_host is NULL). */
+/* 1 when gnode_forward_f32 (method 0, no `keep` buffer) on this graph stores A*Z_I(y_k) in the 4th slab of sol[k],
+ * 1 <= k <= n_steps-1 (see `sol` below), 0 when the 4th slab repeats beta, gamma at every grid point.  n_out: number
+ * of emitted grid points (n_steps+1 when out_rows_host is NULL). */
 int gnode_sol_carries_neighbour_sums(gnode_graph_t g, int32_t H, int32_t n_steps, int32_t n_out);
 /* Size of the optional `keep` buffer of gnode_forward_f32 / gnode_backward_f32 (method 0), or 0 when this H keeps
- * nothing (then pass NULL).  2 * (n_steps + 1) * (rows + 1) * H floats at H = 64 (the tiled and the one-launch form). */
+ * nothing (then pass NULL).  3 * (n_steps + 1) * (rows + 1) * H floats at H = 64 (the tiled and the one-launch form). */
 size_t gnode_forward_keep_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t n_steps, int32_t n_out);
 int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
                       int32_t n_steps, int32_t method, const int32_t* out_rows_host, int32_t n_out,
@@ -137,9 +143,10 @@ int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, co
  * SURVEY Appendix A) followed by autograd through the head and the encoder.
  *   sol          device [n_steps+1, 4*rows, H] saved by gnode_forward_f32 on THIS graph with the
  *                same n_steps / out_rows (its 4th slabs are read as described there)
- *   keep         NULL, or the buffer the SAME gnode_forward_f32 call filled (then every
- *                interval but the last reads the kept activations; gradients agree with
- *                the keep = NULL path to fp32 rounding of the summation order)
+ *   keep         the buffer the SAME gnode_forward_f32 call filled (then every interval
+ *                but the last reads the kept activations; gradients agree with the
+ *                recomputing path to fp32 rounding of the summation order), or NULL for a
+ *                trajectory that was produced without one
  *   gS, gI, gR   device [n_out, rows] upstream gradients of the outputs
  *   grads        device pointers (same struct as the parameters) that RECEIVE
  *                dL/dparam (overwritten, not accumulated)

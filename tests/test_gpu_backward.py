@@ -66,7 +66,8 @@ def test_param_grads_vs_oracle(n, m, B, H, maxTime, deltaT, sub, dev, skewed=Fal
     # both forms of the sweep: over the forward's kept activations (where this path keeps any), and recomputing them
     variants = {"kept": ops.backward(g, x2d, params, dts, "euler", out_rows, sol, *gst)}
     if sol.gnode_keep is not None:
-        variants["recomputed"] = ops.backward(g, x2d, params, dts, "euler", out_rows, sol, *gst, keep=None)
+        _, _, _, sol_nk = ops.forward(g, x2d, params, dts, "euler", out_rows, want_sol=True, want_keep=False)
+        variants["recomputed"] = ops.backward(g, x2d, params, dts, "euler", out_rows, sol_nk, *gst)
     for name, got in variants.items():
         for k in want:
             assert got[k].shape == params[k].shape
@@ -308,8 +309,7 @@ def test_kept_activations_are_the_forwards_and_optional(dev):
     for a, b in ((S1, S0), (I1, I0), (R1, R0)):
         assert torch.equal(a, b)
     assert torch.equal(sol1[:, :3 * rows], sol0[:, :3 * rows])
-    assert torch.equal(sol1[1:G - 1, 3 * rows:], sol0[1:G - 1, 3 * rows:])          # the kept neighbour sums
-    kv = keep.view(G, 2, rows + 1, H)
+    kv = keep.view(G, 3, rows + 1, H)
     W, b = P["odefunc.linear.weight"], P["odefunc.linear.bias"]
     for k in range(G - 1):                                                        # Z_S(y_k): steps 0 .. G-2 evaluate it
         z = torch.sigmoid(sol1[k, :rows].double() @ W.T.double() + b.double())
@@ -318,12 +318,16 @@ def test_kept_activations_are_the_forwards_and_optional(dev):
         z = torch.sigmoid(sol1[k, rows:2 * rows].double() @ W.T.double() + b.double())
         assert float((kv[k, 1, :rows].double() - z).abs().max()) <= 2e-5
         assert float(kv[k, 1, rows].abs().max()) == 0.0                           # the table's zero row
+    for k in range(1, G - 1):                                                     # P_S(y_k) = A Z_I * Z_S (1 - Z_S): the no-keep forward's
+        ai, zs = sol0[k, 3 * rows:], kv[k, 0, :rows]                              # 4th slab holds the A Z_I factor
+        want = ai * (zs * (1.0 - zs))
+        assert float((kv[k, 2, :rows] - want).abs().max()) <= 1e-6 * float(want.abs().max() + 1.0)
     gs = [torch.randn(len(rows_out), rows, device=dev) for _ in range(3)]
     a = ops.backward(g, x, P, dts, "euler", rows_out, sol1, *gs)
-    r = ops.backward(g, x, P, dts, "euler", rows_out, sol1, *gs, keep=None)
-    r0 = ops.backward(g, x, P, dts, "euler", rows_out, sol0, *gs)
+    r = ops.backward(g, x, P, dts, "euler", rows_out, sol0, *gs)
+    with pytest.raises(_lib.GnodeError):                # a trajectory produced WITH keep must come back with it
+        ops.backward(g, x, P, dts, "euler", rows_out, sol1, *gs, keep=None)
     for k in a:
-        assert torch.equal(r[k], r0[k]), k
         if k == "linearS2.bias":
             continue
         scale = float(r[k].abs().max()) + 1e-30

@@ -213,8 +213,9 @@ def test_forward_sol_matches_states(dev):
     P = O.init_params(H, seed=3)
     x = O.make_samples(n, B, H, seed=1)
     g = DeviceGraph(rp, ci)
+    # (without a keep buffer: with one, the neighbour sums go there instead, test_kept_activations_... in test_gpu_backward.py)
     S, I, R, sol = ops.forward(g, torch.from_numpy(x).to(dev).reshape(B * n, 3 + H), _tp(P, dev),
-                               ops.step_sizes(ops.time_grid(5, 0.5)), want_sol=True)
+                               ops.step_sizes(ops.time_grid(5, 0.5)), want_sol=True, want_keep=False)
     So, Io, Ro, sol_o = O.odeblock_forward_single(x, P, rp, ci, 5, 0.5, return_sol=True)
     assert tuple(sol.shape) == sol_o.shape
     q = 3 * B * n
