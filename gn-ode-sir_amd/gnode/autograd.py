@@ -34,7 +34,8 @@ class _GNODEForward(torch.autograd.Function):
         gS, gI, gR = (torch.zeros_like(ref) if g is None else g for g in (gS, gI, gR))
         grads = ops.backward(ctx.graph, x2d, params, ctx.dts, ctx.method, ctx.out_rows, sol,
                              gS.contiguous(), gI.contiguous(), gR.contiguous(), keep=ctx.keep)
-        ctx.keep = None
+        # (ctx.keep stays: a second backward through this node -- retain_graph=True, two losses on one forward --
+        #  needs it again; it is freed with ctx and sol)
         return (None, None, None, None, None, None, *[grads[k] for k in ctx.keys])
 
 

@@ -15,6 +15,12 @@ PARAM_KEYS = ("odefunc.linear.weight", "odefunc.linear.bias", "linearS1.weight",
 
 METHODS = {"euler": 0, "rk4": 1}
 
+# Kept activations for the adjoint backward (include/gnode.h: `keep`): on unless GNODE_KEEP=0, read ONCE at import.
+# Cost: 3 * (n_steps + 1) * (rows + 1) * 64 floats on top of the trajectory's 4 slabs per grid point (+75 % activation
+# memory: 75k nodes x 8 samples x 59 steps = 36.9 GB of trajectory + 27.6 GB kept); when that allocation fails the
+# forward falls back to the recomputing backward's layout (no keep buffer) instead of raising.
+KEEP_DEFAULT = os.environ.get("GNODE_KEEP", "1") != "0"
+
 
 def time_grid(maxTime, deltaT) -> np.ndarray:
     """float64 np.arange(0, maxTime, deltaT): reference ode_nn_ngraph_sim.py:110."""
@@ -70,7 +76,7 @@ def rhs(graph: DeviceGraph, x: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -
 
 def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray, method: str = "euler",
             out_rows: np.ndarray | None = None, want_sol: bool = False, workspace: torch.Tensor | None = None,
-            want_keep: bool = True):
+            want_keep: bool | None = None):
     """ODEBlock.forward on x2d [rows, 3+H]; returns (S, I, R) each [n_out, rows] and sol or None.
 
     With want_sol (training) and want_keep, the kept activations the adjoint backward reads back (include/gnode.h: `keep`)
@@ -94,10 +100,15 @@ def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray
     ws = workspace if (workspace is not None and workspace.numel() >= need) else _workspace(need, dev)
     p = pack_params(params)
     keep = None
-    if sol is not None and want_keep and m == 0 and os.environ.get("GNODE_KEEP", "1") != "0":
+    if want_keep is None:
+        want_keep = KEEP_DEFAULT
+    if sol is not None and want_keep and m == 0:
         kb = lib.gnode_forward_keep_bytes(graph.handle, rows, H, n_steps, n_out)
         if kb:
-            keep = torch.empty(kb // 4, dtype=torch.float32, device=dev)
+            try:
+                keep = torch.empty(kb // 4, dtype=torch.float32, device=dev)
+            except torch.cuda.OutOfMemoryError:
+                keep = None                      # the recomputing backward needs only the trajectory
     _lib.check(lib.gnode_forward_f32(
         graph.handle, _lib.ptr(x2d), C.byref(p), _lib.host_ptr(dts), n_steps, m,
         _lib.host_ptr(out_rows) if out_rows is not None else None, n_out,

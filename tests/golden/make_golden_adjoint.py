@@ -16,6 +16,12 @@ integrator does.
   adjoint_karate_H64_T20.npz   karate club, B = 2, H = 64, maxTime = 20, deltaT = 0.5 (the reference's shipped shape)
   adjoint_er200_H64_T6.npz     Erdos-Renyi G(200, 700) giant component, B = 2, H = 64, maxTime = 6
   adjoint_loops40_H8_T5.npz    40-node graph with self-loops, B = 3, H = 8, maxTime = 5
+  adjoint_fb_H64_T30.npz       Erdos-Renyi G(1 893, 13 835) (fb-social's counts, configs[1]), B = 1, H = 64, maxTime = 30,
+                               deltaT = 0.5 -> the FULL 59-interval adjoint the reference trains through
+  adjoint_wiki_H64_T30.npz     Erdos-Renyi G(7 066, 100 736) (wiki-vote's counts, configs[2]), same horizon
+      (graph by seed from gnode/synth.py instead of an edge list; besides the float64 gradients "G:<name>" these two hold
+       three of the 30 output rows the loss saw ("rows_kept"), and "G32:<name>": the SAME reference classes and adjoint rule run under torch.float32 -- the yardstick that says how
+       far the reference's own fp32 training gradient sits from float64 after 59 intervals)
 Each: inputs by seed (gnode/synth.py generators), the edge list, and the outputs at the kept rows and the 8 parameter gradients in float64 (the reference
 classes run under torch.float64: a yardstick the fp32 kernels are held to at 2e-4, like the oracle comparisons) and
 the loss value.
@@ -119,6 +125,42 @@ def main():
         np.savez_compressed(os.path.join(HERE, tag + ".npz"), **d)
         print("wrote", tag, "loss", loss.item(), "|gW|", float(np.abs(d["G:odefunc.linear.weight"]).max()))
     torch.set_default_dtype(torch.float32)
+
+    # ---- full horizon (59 intervals) at the fb-social / wiki-vote node and edge counts
+    import scipy.sparse as sp
+    for tag, n, m in [("fb", 1893, 13835), ("wiki", 7066, 100736)]:
+        H, maxTime, deltaT, B = 64, 30, 0.5, 1
+        rp, ci = synth.er_csr(n, m, seed=0)
+        A = sp.csr_matrix((np.ones(ci.shape[0], dtype=np.int64), ci, rp), shape=(n, n))
+        P = synth.linear_params(H, seed=0)
+        x = synth.samples(n, B, H, seed=1000)
+        d = dict(n=np.int32(n), m=np.int32(m), graph_seed=np.int32(0), B=np.int32(B), H=np.int32(H), maxTime=np.int32(maxTime),
+                 deltaT=np.float64(deltaT), param_seed=np.int32(0), sample_seed=np.int32(1000))
+        for dtype, pre in [(torch.float64, "G:"), (torch.float32, "G32:")]:
+            torch.set_default_dtype(dtype)
+            f = single.ODEfunc(A, 0.2, 0.1, H, dev)
+            mdl = single.ODEBlock(maxTime, deltaT, n, [0], H, f, dev)
+            set_params(mdl, P, dtype)
+            y = torch.from_numpy(closed_form_labels(B, n, maxTime)).to(torch.float64)
+            mdl.zero_grad()
+            S, I, R = mdl(torch.from_numpy(x).to(dtype))
+            loss = ref_loss(helpers, S, I, R, y, maxTime, deltaT)
+            loss.backward()
+            named = dict(mdl.named_parameters())
+            for k in keys:
+                d[pre + k] = named[k].grad.detach().numpy().astype(np.float64)
+            if dtype == torch.float64:
+                d["loss"] = np.float64(loss.item())
+                sub = lambda a: helpers.get_sir_t_nodes_torch(torch.squeeze(a), maxTime, deltaT, count=False).detach().numpy()
+                d["rows_kept"] = np.asarray([1, 15, 29], dtype=np.int32)     # of the maxTime rows the loss sees (the full-size forward is pinned by full_*.npz)
+                d["S"], d["I"], d["R"] = (sub(S)[d["rows_kept"]], sub(I)[d["rows_kept"]], sub(R)[d["rows_kept"]])
+            else:
+                d["loss32"] = np.float64(loss.item())
+        torch.set_default_dtype(torch.float32)
+        rel = {k: float(np.abs(d["G32:" + k] - d["G:" + k]).max() / max(np.abs(d["G:" + k]).max(), 1e-30)) for k in keys}
+        name = f"adjoint_{tag}_H64_T30"
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print("wrote", name, "loss", d["loss"], "reference fp32 vs float64 gradient, rel:", {k: f"{v:.1e}" for k, v in rel.items()})
 
 
 if __name__ == "__main__":
