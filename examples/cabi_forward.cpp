@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     hipStream_t st;
     HK(hipStreamCreate(&st));
     CK(gnode_forward_f32(g, dx, &p, dt.data(), n_steps, 0, nullptr, 0, dout, dout + (size_t)G * rows, dout + (size_t)2 * G * rows,
-                         nullptr /* sol */, nullptr /* keep */, 0, rows, H, ws, ws_bytes, st));
+                         nullptr /* sol */, nullptr /* keep */, 0, rows, H, ws, ws_bytes, st, 0 /* flags */, nullptr /* sol_info */));
     HK(hipStreamSynchronize(st));
     std::vector<float> out((size_t)3 * G * rows);
     HK(hipMemcpy(out.data(), dout, out.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
     }
     printf("n=%d B=%d G=%d sumS=%.6f sumI=%.6f max|S+I+R-1|=%.2e\n", n, B, G, sumS, sumI, dev1);
     // bad argument -> error code + message, no crash
-    const int rc = gnode_forward_f32(g, dx, &p, dt.data(), n_steps, 0, nullptr, 0, dout, dout, dout, nullptr, nullptr, 0, rows + 1, H, ws, ws_bytes, st);
+    const int rc = gnode_forward_f32(g, dx, &p, dt.data(), n_steps, 0, nullptr, 0, dout, dout, dout, nullptr, nullptr, 0, rows + 1, H, ws, ws_bytes, st, 0, nullptr);
     printf("bad rows -> rc=%d (%s)\n", rc, gnode_last_error());
     CK(gnode_graph_destroy(g));
     return dev1 < 1e-5 && rc == GNODE_ERR_ARG ? 0 : 2;

@@ -1143,7 +1143,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                                   int32_t n_steps, const int32_t* out_rows_host, int32_t n_out, const float* sol,
                                   const float* keep, size_t keep_bytes, const float* gS, const float* gI, const float* gR,
                                   const gnode_params* grads, int64_t rows, int32_t H, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+                                  size_t workspace_bytes, void* stream, int32_t sol_info) {
     GN_CHECK_ARG(g && x && p && sol && gS && gI && gR && grads && workspace, "gnode_backward_f32: null pointer");
     GN_CHECK_ARG(n_steps >= 0 && (n_steps == 0 || dt_host), "gnode_backward_f32: bad n_steps/dt");
     GN_CHECK_ARG(H >= 4 && H <= 128 && H % 4 == 0, "gnode_backward_f32: need 4 <= H <= 128, H %% 4 == 0 (got %d)", H);
@@ -1230,6 +1230,13 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         const bool ai_saved = gn_sol_carries_ai(g, H, n_steps, out_rows_host ? n_out : G);
         // ... and did the forward keep Z_S(y_k), Z_I(y_k) as well?  Then the intervals below the last read them back
         const size_t keep_need = gnode_forward_keep_bytes(g, rows, H, n_steps, out_rows_host ? n_out : G);
+        if (sol_info >= 0) {
+            // the forward said what it left in `sol` / `keep` (sol_info_host): a trajectory and a keep buffer belong together
+            if (keep) GN_CHECK_ARG(sol_info & GNODE_SOL_KEEP, "gnode_backward_f32: a keep buffer was passed with a trajectory whose "
+                                   "forward call filled none (sol_info %d)", sol_info);
+            else if (ai_saved) GN_CHECK_ARG(sol_info & GNODE_SOL_AI, "gnode_backward_f32: this trajectory was produced WITH a keep buffer "
+                                            "(its 4th slabs are unwritten): pass that buffer (sol_info %d)", sol_info);
+        }
         if (!(ai_saved && keep_need > 0)) keep = nullptr;
         if (keep && keep_bytes < keep_need) {
             gnode_set_error("gnode_backward_f32: keep buffer %zu < %zu", keep_bytes, keep_need);

@@ -26,7 +26,7 @@ void gnode_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gnode_last_error(void) { return g_err; }
-extern "C" int gnode_version(void) { return 210; }   // 200: workspace sizes take the graph handle (hub scratch is carved from the caller's workspace); 210: forward / backward take the optional kept-activation buffer
+extern "C" int gnode_version(void) { return 220; }   // 220: forward takes flags + reports what sol / keep carry (sol_info), backward checks it; persistent one-launch path for mid-size graphs; 200: workspace sizes take the graph handle (hub scratch is carved from the caller's workspace); 210: forward / backward take the optional kept-activation buffer
 
 // --------------------------------------------------------------------------- instrumentation
 // HIP-event pairs around every launch of the two step kernels while enabled
@@ -505,6 +505,7 @@ static int launch_readout(const float* Y, long rows, int H, const gnode_params* 
 // never inside a stream capture): dynamic-LDS attributes of every kernel that can ask for more than 64 KB, and the
 // device's CU count.  The only process-wide state besides the opt-in profiler: write-once per device, under a lock.
 #include <mutex>
+#include "gnode_pers64.h"
 static std::mutex g_dev_mu;
 static bool g_dev_done[64] = {};
 static int g_dev_cu[64] = {};
@@ -517,6 +518,7 @@ int gn_device_setup_once(int dev) {
     g_dev_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (int e = gn_ode_set_attributes()) return e;
     if (int e = gn_h64_set_attributes()) return e;
+    if (int e = gn_pers64_set_attributes()) return e;
     if (int e = gn_h128_set_attributes()) return e;
     if (int e = gn_bwd_set_attributes()) return e;
     if (int e = gn_bwd_tiny_set_attributes()) return e;
@@ -650,7 +652,12 @@ static size_t forward_fixed_bytes(int64_t rows, int32_t H, int32_t method) {
     if (method == 1) nslab += 3 * 5;        // k1..k4, ytmp (3 slabs each)
     // + one 256-B ZERO ROW behind each of the two gather tables (H = 64 step kernel: rows shorter than the gather
     //   width read it instead of branching per neighbour)
-    return nslab * slab + 512 + 2 * gn_align((size_t)rows * sizeof(float)) + gn_align((size_t)rows * 4 * sizeof(float));
+    // + the control block of the persistent one-launch path (gnode_pers64.hip): tickets, barrier flags, give-up word
+    return nslab * slab + 512 + 2 * gn_align((size_t)rows * sizeof(float)) + gn_align((size_t)rows * 4 * sizeof(float)) +
+           (H == 64 ? gn_pers64_ctl_bytes() : 0);
+}
+static char* forward_ctl_ptr(void* workspace, int64_t rows, int32_t H, int32_t method) {
+    return (char*)workspace + forward_fixed_bytes(rows, H, method) - gn_pers64_ctl_bytes();
 }
 
 extern "C" size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t method) {
@@ -661,7 +668,7 @@ extern "C" size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, i
 extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
                                  int32_t n_steps, int32_t method, const int32_t* out_rows_host, int32_t n_out, float* S,
                                  float* I, float* R, float* sol, float* keep, size_t keep_bytes, int64_t rows, int32_t H,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+                                 void* workspace, size_t workspace_bytes, void* stream, int32_t flags, int32_t* sol_info_host) {
     GN_CHECK_ARG(g && x && p && S && I && R && workspace, "gnode_forward_f32: null pointer");
     GN_CHECK_ARG(n_steps >= 0 && (n_steps == 0 || dt_host), "gnode_forward_f32: bad n_steps/dt");
     GN_CHECK_ARG(method == 0 || method == 1, "gnode_forward_f32: method must be 0 (euler) or 1 (rk4)");
@@ -690,6 +697,10 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         gnode_set_error("gnode_forward_f32: keep buffer %zu < %zu", keep_bytes,
                         gnode_forward_keep_bytes(g, rows, H, n_steps, out_rows_host ? n_out : G));
         return GNODE_ERR_WORKSPACE;
+    }
+    if (sol_info_host) {                         // what this call leaves in `sol` / `keep`: gnode_backward_f32 checks it
+        const int n_emit = out_rows_host ? n_out : G;
+        *sol_info_host = !sol ? 0 : (keep ? GNODE_SOL_KEEP : (method == 0 && gn_sol_carries_ai(g, H, n_steps, n_emit) ? GNODE_SOL_AI : 0));
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t slab = (size_t)rows * H, slab_b = gn_align(slab * sizeof(float));
@@ -748,6 +759,18 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
             hipLaunchKernelGGL(k_fill_bg, dim3((unsigned)std::min<size_t>((slab4 + 255) / 256, 2048)), dim3(256), 0, st, sol, slab4, G);
             GN_LAUNCH_CHECK();
         }
+        return 0;
+    }
+    PersPlan plan;
+    if (h64 && !(flags & GNODE_FWD_PER_STEP) && gn_pers64_plan(g, rows / g->n, n_steps, &plan)) {
+        // mid-size graphs: ONE persistent launch, every workgroup keeps its rows in registers for all steps (gnode_pers64.hip)
+        int slots[128];
+        for (int k = 0; k < n_steps; ++k) slots[k] = out_slot(k + 1);
+        const bool sampled = prof_begin(0, st);
+        if (int e = gn_launch_pers64(g, plan, rows, Y, PR, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,
+                                     gamma, dt_host, slots, n_steps, p, S, I, R, sol, keep, forward_ctl_ptr(workspace, rows, H, method), st))
+            return e;
+        if (sampled) prof_mark(0, st);
         return 0;
     }
 
@@ -828,6 +851,33 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         hipLaunchKernelGGL(k_fill_bg, dim3((unsigned)std::min<size_t>((slab4 + 255) / 256, 2048)), dim3(256), 0, st, sol, slab4, G);
         GN_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" int gnode_forward_path(gnode_graph_t g, int64_t rows, int32_t H, int32_t method, int32_t n_steps, int32_t n_out,
+                                  int32_t with_sol, int32_t flags, int32_t* plan_host) {
+    if (!g || rows <= 0 || rows % g->n) return -1;
+    if (!(H == 64 && method == 0) || n_steps < 1) return 0;
+    if (gn_tiny64_ok(g->n, n_steps, n_out, !with_sol)) return 1;
+    PersPlan pl;
+    if (!(flags & GNODE_FWD_PER_STEP) && gn_pers64_plan(g, rows / g->n, n_steps, &pl)) {
+        if (plan_host) { plan_host[0] = pl.nt; plan_host[1] = pl.wgs; plan_host[2] = pl.span; plan_host[3] = pl.gpx; plan_host[4] = pl.concurrent; }
+        return 2;
+    }
+    return 0;
+}
+
+extern "C" int gnode_forward_status(gnode_graph_t g, int64_t rows, int32_t H, int32_t method, const void* workspace, void* stream,
+                                    int32_t* code_host) {
+    GN_CHECK_ARG(g && workspace && code_host, "gnode_forward_status: null pointer");
+    *code_host = 0;
+    if (H != 64) return 0;
+    unsigned err[2] = {0, 0};
+    const PersCtl* ctl = (const PersCtl*)forward_ctl_ptr(const_cast<void*>(workspace), rows, H, method);
+    GN_HIP(hipMemcpyAsync(err, ctl->error, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GN_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *code_host = (int32_t)err[0];
+    if (err[0]) gnode_set_error("persistent forward: a workgroup gave up waiting for epoch %u of its group", err[1]);
     return 0;
 }
 

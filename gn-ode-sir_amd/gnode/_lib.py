@@ -17,7 +17,7 @@ EXPORTS = [
     "gnode_last_error", "gnode_version",
     "gnode_graph_create", "gnode_graph_destroy", "gnode_graph_info",
     "gnode_rhs_workspace_bytes", "gnode_rhs_f32",
-    "gnode_forward_workspace_bytes", "gnode_forward_f32", "gnode_sol_carries_neighbour_sums", "gnode_forward_keep_bytes",
+    "gnode_forward_workspace_bytes", "gnode_forward_f32", "gnode_forward_status", "gnode_forward_path", "gnode_sol_carries_neighbour_sums", "gnode_forward_keep_bytes",
     "gnode_backward_workspace_bytes", "gnode_backward_f32",
     "gnode_sir_workspace_bytes", "gnode_sir_coins_workspace_bytes",
     "gnode_sir_mc_philox", "gnode_sir_mc_philox_scan", "gnode_sir_mc_coins",
@@ -71,7 +71,11 @@ def load():
     lib.gnode_sol_carries_neighbour_sums.restype = C.c_int
     lib.gnode_forward_keep_bytes.argtypes = [vp, i64, i32, i32, i32]
     lib.gnode_forward_keep_bytes.restype = sz
-    lib.gnode_forward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, sz, i64, i32, vp, sz, vp]
+    lib.gnode_forward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, sz, i64, i32, vp, sz, vp, i32, C.POINTER(i32)]
+    lib.gnode_forward_status.argtypes = [vp, i64, i32, i32, vp, vp, C.POINTER(i32)]
+    lib.gnode_forward_status.restype = C.c_int
+    lib.gnode_forward_path.argtypes = [vp, i64, i32, i32, i32, i32, i32, i32, C.POINTER(i32)]
+    lib.gnode_forward_path.restype = C.c_int
     lib.gnode_meanfield_workspace_bytes.argtypes = [vp]
     lib.gnode_meanfield_workspace_bytes.restype = sz
     lib.gnode_meanfield_f64.argtypes = [vp, vp, i32, C.c_double, vp, vp, i32, C.c_double, C.c_double, vp, vp, vp,
@@ -86,7 +90,7 @@ def load():
     lib.gnode_backward_workspace_bytes.argtypes = [vp, i64, i32]
     lib.gnode_backward_workspace_bytes.restype = sz
     lib.gnode_backward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, vp, i32, vp, vp, sz, vp, vp, vp,
-                                       C.POINTER(Params), i64, i32, vp, sz, vp]
+                                       C.POINTER(Params), i64, i32, vp, sz, vp, i32]
     lib.gnode_backward_f32.restype = C.c_int
     lib.gnode_sir_workspace_bytes.argtypes = [vp, i32]
     lib.gnode_sir_workspace_bytes.restype = sz
@@ -102,8 +106,8 @@ def load():
     for fn in ("gnode_graph_create", "gnode_graph_destroy", "gnode_graph_info", "gnode_rhs_f32", "gnode_forward_f32",
                "gnode_sir_mc_philox", "gnode_sir_mc_coins"):
         getattr(lib, fn).restype = C.c_int
-    if lib.gnode_version() < 210:
-        raise GnodeError(f"{LIB_PATH} is stale (ABI {lib.gnode_version()} < 210): rebuild it (gnode.build.build_lib)")
+    if lib.gnode_version() < 220:
+        raise GnodeError(f"{LIB_PATH} is stale (ABI {lib.gnode_version()} < 220): rebuild it (gnode.build.build_lib)")
     _lib = lib
     return lib
 

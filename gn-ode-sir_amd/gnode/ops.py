@@ -20,6 +20,10 @@ METHODS = {"euler": 0, "rk4": 1}
 # memory: 75k nodes x 8 samples x 59 steps = 36.9 GB of trajectory + 27.6 GB kept); when that allocation fails the
 # forward falls back to the recomputing backward's layout (no keep buffer) instead of raising.
 KEEP_DEFAULT = os.environ.get("GNODE_KEEP", "1") != "0"
+# The persistent one-launch integration of mid-size graphs (csrc/gnode_pers64.hip; include/gnode.h: GNODE_FWD_PER_STEP):
+# on unless GNODE_PERSIST=0, read once at import.  Same outputs bit for bit either way.
+PERSIST_DEFAULT = os.environ.get("GNODE_PERSIST", "1") != "0"
+FWD_PER_STEP = 1
 
 
 def time_grid(maxTime, deltaT) -> np.ndarray:
@@ -76,7 +80,7 @@ def rhs(graph: DeviceGraph, x: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -
 
 def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray, method: str = "euler",
             out_rows: np.ndarray | None = None, want_sol: bool = False, workspace: torch.Tensor | None = None,
-            want_keep: bool | None = None):
+            want_keep: bool | None = None, persist: bool | None = None):
     """ODEBlock.forward on x2d [rows, 3+H]; returns (S, I, R) each [n_out, rows] and sol or None.
 
     With want_sol (training) and want_keep, the kept activations the adjoint backward reads back (include/gnode.h: `keep`)
@@ -109,15 +113,39 @@ def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray
                 keep = torch.empty(kb // 4, dtype=torch.float32, device=dev)
             except torch.cuda.OutOfMemoryError:
                 keep = None                      # the recomputing backward needs only the trajectory
+    info = C.c_int32(0)
     _lib.check(lib.gnode_forward_f32(
         graph.handle, _lib.ptr(x2d), C.byref(p), _lib.host_ptr(dts), n_steps, m,
         _lib.host_ptr(out_rows) if out_rows is not None else None, n_out,
         _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(sol) if sol is not None else None,
         _lib.ptr(keep) if keep is not None else None, keep.numel() * 4 if keep is not None else 0,
-        rows, H, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        rows, H, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(),
+        0 if (PERSIST_DEFAULT if persist is None else persist) else FWD_PER_STEP, C.byref(info)))
     if sol is not None:
         sol.gnode_keep = keep
+        sol.gnode_info = int(info.value)         # what the call left in sol / keep: the backward checks the pairing
+    forward.last_workspace = (graph, rows, H, m, ws, n_steps, n_out, sol is not None, persist)
     return out[0], out[1], out[2], sol
+
+
+def forward_path(graph: DeviceGraph, rows: int, H: int, n_steps: int, n_out: int | None = None, want_sol: bool = False,
+                 method: str = "euler", persist: bool | None = None):
+    """(path, plan): 0 = one launch per Euler step, 1 = one-workgroup launch (tiny graphs), 2 = persistent launch with
+    plan = (tiles per workgroup, workgroups per sample, XCDs per sample, samples per XCD, samples alive at once)."""
+    plan = (C.c_int32 * 8)()
+    path = _lib.load().gnode_forward_path(graph.handle, rows, H, METHODS[method], n_steps, n_steps + 1 if n_out is None else n_out,
+                                          int(want_sol), 0 if (PERSIST_DEFAULT if persist is None else persist) else FWD_PER_STEP, plan)
+    return int(path), tuple(int(v) for v in plan[:5])
+
+
+def forward_status() -> int:
+    """0, or the give-up code of the persistent launch behind the LAST `forward` call (synchronises the stream)."""
+    graph, rows, H, m, ws, n_steps, n_out, want_sol, persist = forward.last_workspace
+    if forward_path(graph, rows, H, n_steps, n_out, want_sol, "euler" if m == 0 else "rk4", persist)[0] != 2:
+        return 0                                 # (the control block is only written by the persistent launch)
+    code = C.c_int32(0)
+    _lib.check(_lib.load().gnode_forward_status(graph.handle, rows, H, m, _lib.ptr(ws), _lib.stream_ptr(), C.byref(code)))
+    return int(code.value)
 
 
 def backward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray, method: str, out_rows, sol: torch.Tensor,
@@ -153,7 +181,7 @@ def backward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarra
         _lib.host_ptr(out_rows) if out_rows is not None else None, n_out, _lib.ptr(_f32c(sol)),
         _lib.ptr(keep) if keep is not None else None, keep.numel() * 4 if keep is not None else 0,
         _lib.ptr(_f32c(gS)), _lib.ptr(_f32c(gI)), _lib.ptr(_f32c(gR)), C.byref(gp), rows, H,
-        _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), int(getattr(sol, "gnode_info", -1))))
     return grads
 
 

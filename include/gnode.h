@@ -123,8 +123,34 @@ int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* 
  *              do not depend on whether keep is given.  A trajectory and the keep buffer
  *              of the same call belong together: hand gnode_backward_f32 both, or a
  *              trajectory that was produced WITHOUT keep and NULL.
- *   workspace  device, >= gnode_forward_workspace_bytes(g, rows, H, method) */
+ *   workspace  device, >= gnode_forward_workspace_bytes(g, rows, H, method)
+ *   flags      0, or GNODE_FWD_PER_STEP: never take the persistent one-launch path (below)
+ *   sol_info_host  NULL, or host int32 that receives what this call leaves in `sol` / `keep`
+ *              (GNODE_SOL_AI: the 4th slabs of sol[1 .. n_steps-1] carry A*Z_I; GNODE_SOL_KEEP: the
+ *              keep buffer was filled and those slabs are unwritten; 0: neither): hand it to
+ *              gnode_backward_f32, which then refuses a trajectory / keep pair that does not
+ *              belong together instead of reading unwritten memory.
+ * Mid-size graphs at H = 64 (a few hundred to ~16k rows per launch, no rows longer than the hub
+ * threshold, <= 128 steps): the whole integration runs as ONE persistent launch in which every
+ * workgroup keeps its rows in registers across all steps and the workgroups of a sample meet at an
+ * in-launch barrier once per step.  Its spins are bounded: gnode_forward_status() reports a
+ * workgroup that gave up (never observed; it exists so that a hang becomes an error).  Same
+ * outputs, bit for bit, as the one-launch-per-step form. */
+#define GNODE_FWD_PER_STEP 1
+#define GNODE_SOL_AI 1
+#define GNODE_SOL_KEEP 2
 size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t method);
+/* Which form gnode_forward_f32 runs for this shape: 0 = one launch per step, 1 = the one-workgroup-per-sample launch of
+ * tiny graphs, 2 = the persistent launch of mid-size graphs (then plan_host, if given, receives {16-row tiles per
+ * workgroup, workgroups per sample, XCDs per sample, samples side by side per XCD, samples alive at once}); -1 = bad
+ * arguments.  n_out: emitted grid points; with_sol: a trajectory is requested (training). */
+int gnode_forward_path(gnode_graph_t g, int64_t rows, int32_t H, int32_t method, int32_t n_steps, int32_t n_out,
+                       int32_t with_sol, int32_t flags, int32_t* plan_host);
+/* Synchronises `stream` and writes 0 to *code_host, or the give-up code of the last gnode_forward_f32 call that ran the
+ * persistent path on this workspace (then its outputs are invalid).  Meaningful only after a call for which
+ * gnode_forward_path() says 2 (the other forms never touch the control block).  Not capturable. */
+int gnode_forward_status(gnode_graph_t g, int64_t rows, int32_t H, int32_t method, const void* workspace, void* stream,
+                         int32_t* code_host);
 /* 1 when gnode_forward_f32 (method 0, no `keep` buffer) on this graph stores A*Z_I(y_k) in the 4th slab of sol[k],
  * 1 <= k <= n_steps-1 (see `sol` below), 0 when the 4th slab repeats beta, gamma at every grid point.  n_out: number
  * of emitted grid points (n_steps+1 when out_rows_host is NULL). */
@@ -135,7 +161,8 @@ size_t gnode_forward_keep_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_
 int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, const float* dt_host,
                       int32_t n_steps, int32_t method, const int32_t* out_rows_host, int32_t n_out,
                       float* S, float* I, float* R, float* sol, float* keep, size_t keep_bytes,
-                      int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream);
+                      int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream,
+                      int32_t flags, int32_t* sol_info_host);
 
 /* ---- backward -------------------------------------------------------------
  * The gradient the reference trains with: torchdiffeq's odeint_adjoint under
@@ -147,6 +174,8 @@ int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, co
  *                but the last reads the kept activations; gradients agree with the
  *                recomputing path to fp32 rounding of the summation order), or NULL for a
  *                trajectory that was produced without one
+ *   sol_info     what gnode_forward_f32 reported through sol_info_host for that call (checked against
+ *                `keep`: GNODE_ERR_ARG on a mismatch), or -1 = unchecked (the caller vouches for the pairing)
  *   gS, gI, gR   device [n_out, rows] upstream gradients of the outputs
  *   grads        device pointers (same struct as the parameters) that RECEIVE
  *                dL/dparam (overwritten, not accumulated)
@@ -157,7 +186,8 @@ int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_params* p, c
                        int32_t n_steps, const int32_t* out_rows_host, int32_t n_out, const float* sol,
                        const float* keep, size_t keep_bytes,
                        const float* gS, const float* gI, const float* gR, const gnode_params* grads,
-                       int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream);
+                       int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream,
+                       int32_t sol_info);
 
 /* ---- Monte-Carlo SIR labels ------------------------------------------------
  * sir_torch(G, seed_set, beta, gamma, sims, T): ode_nn.py:30-88.

@@ -1,0 +1,127 @@
+"""The persistent one-launch integration of mid-size graphs (csrc/gnode_pers64.hip) against the one-launch-per-step
+form of the same library: outputs, trajectory and kept activations must agree BIT FOR BIT (same arithmetic, same
+summation order, same MFMA chains), for every placement shape the plan produces -- one sample per XCD, several samples
+per XCD, a sample across 2 / 4 / 8 XCDs -- in inference and in training.  Parity with the reference itself is held by
+test_gpu_parity.py / test_gpu_backward.py, which run through the persistent path by default at these sizes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _setup(n, m, B, seed, dev):
+    import torch
+    from gnode import ops, synth
+    from gnode.graph import DeviceGraph
+    rp, ci = synth.er_csr(n, m, seed=seed)
+    g = DeviceGraph(rp, ci)
+    P = {k: torch.from_numpy(v).to(dev) for k, v in synth.linear_params(64, seed=seed + 1).items()}
+    x = torch.from_numpy(synth.samples(n, B, 64, seed=seed + 2)).to(dev).reshape(B * n, 67)
+    return g, P, x
+
+
+# (n, undirected edges, samples, expected XCDs per sample)
+SHAPES = [(1893, 13835, 1, 4), (1893, 13835, 8, 1), (1893, 13835, 3, 2), (600, 2400, 5, 1), (300, 1500, 16, 1),
+          (7066, 100736, 1, 8), (7066, 100736, 2, 4), (130, 500, 2, 1), (4099, 30000, 2, 4)]
+
+
+@pytest.mark.parametrize("n,m,B,span", SHAPES)
+def test_persistent_inference_bitwise(n, m, B, span, dev):
+    import torch
+    from gnode import ops
+    g, P, x = _setup(n, m, B, 7, dev)
+    maxTime, deltaT = 30, 0.5
+    dts = ops.step_sizes(ops.time_grid(maxTime, deltaT))
+    path, plan = ops.forward_path(g, B * n, 64, len(dts))
+    assert path == 2 and plan[2] == span, (path, plan)
+    for out_rows in (None, ops.subsample_rows(maxTime, deltaT)):
+        S0, I0, R0, _ = ops.forward(g, x, P, dts, "euler", out_rows, persist=False)
+        S1, I1, R1, _ = ops.forward(g, x, P, dts, "euler", out_rows, persist=True)
+        assert ops.forward_status() == 0
+        for a, b in ((S0, S1), (I0, I1), (R0, R1)):
+            assert torch.equal(a, b), float((a - b).abs().max())
+    # the same launch again on the same workspace shape (fresh tickets / flags every call) and with unequal steps
+    dts2 = np.asarray([0.5, 0.25, 1.0, 0.5, 0.125, 0.5, 0.5], dtype=np.float32)
+    S0, I0, R0, _ = ops.forward(g, x, P, dts2, "euler", np.asarray([0, 3, 7], dtype=np.int32), persist=False)
+    S1, I1, R1, _ = ops.forward(g, x, P, dts2, "euler", np.asarray([0, 3, 7], dtype=np.int32), persist=True)
+    assert ops.forward_status() == 0
+    assert torch.equal(S0, S1) and torch.equal(I0, I1) and torch.equal(R0, R1)
+
+
+@pytest.mark.parametrize("keep", [True, False], ids=["kept", "nokeep"])
+@pytest.mark.parametrize("n,m,B,span", [(1893, 13835, 1, 4), (1893, 13835, 8, 1), (600, 2400, 5, 1), (7066, 100736, 1, 8)])
+def test_persistent_training_forward_bitwise(n, m, B, span, keep, dev):
+    import torch
+    from gnode import ops
+    g, P, x = _setup(n, m, B, 11, dev)
+    maxTime, deltaT = 12, 0.5
+    dts = ops.step_sizes(ops.time_grid(maxTime, deltaT))
+    rows_out = ops.subsample_rows(maxTime, deltaT)
+    assert ops.forward_path(g, B * n, 64, len(dts), len(rows_out), want_sol=True)[0] == 2
+    rows = B * n
+    # poison what each form leaves unwritten the same way, so that whole buffers can be compared
+    outs = []
+    for persist in (False, True):
+        S, I, R, sol = ops.forward(g, x, P, dts, "euler", rows_out, want_sol=True, want_keep=keep, persist=persist)
+        assert ops.forward_status() == 0
+        outs.append((S, I, R, sol, sol.gnode_keep, sol.gnode_info))
+    (S0, I0, R0, sol0, k0, i0), (S1, I1, R1, sol1, k1, i1) = outs
+    assert i0 == i1 == (2 if keep else 1)
+    assert torch.equal(S0, S1) and torch.equal(I0, I1) and torch.equal(R0, R1)
+    G = len(dts) + 1
+    assert torch.equal(sol0[:, :3 * rows], sol1[:, :3 * rows])                         # odeint's S, I, R slabs at every grid point
+    assert torch.equal(sol0[0, 3 * rows:], sol1[0, 3 * rows:])                         # beta, gamma at grid point 0
+    if keep:
+        st = (rows + 1) * 64
+        a, b = k0.view(G, 3, st), k1.view(G, 3, st)
+        assert torch.equal(a[:G - 1, 0, :rows * 64], b[:G - 1, 0, :rows * 64])         # Z_S(y_k), k < n_steps
+        assert torch.equal(a[:, 1], b[:, 1])                                           # Z_I tables incl. their zero rows
+        assert torch.equal(a[1:G - 1, 2, :rows * 64], b[1:G - 1, 2, :rows * 64])       # P_S(y_k), 1 <= k < n_steps
+    else:
+        assert torch.equal(sol0[1:G - 1, 3 * rows:], sol1[1:G - 1, 3 * rows:])         # A Z_I(y_k) parked in the 4th slabs
+
+
+def test_persistent_training_gradient(dev):
+    """backward over what the persistent training forward kept == backward over the per-step forward's, bit for bit"""
+    import torch
+    from gnode import ops
+    n, m, B = 1893, 13835, 2
+    g, P, x = _setup(n, m, B, 5, dev)
+    maxTime, deltaT = 30, 0.5
+    dts = ops.step_sizes(ops.time_grid(maxTime, deltaT))
+    rows_out = ops.subsample_rows(maxTime, deltaT)
+    gs = [torch.randn(len(rows_out), B * n, device=dev) for _ in range(3)]
+    grads = []
+    for persist in (False, True):
+        S, I, R, sol = ops.forward(g, x, P, dts, "euler", rows_out, want_sol=True, persist=persist)
+        grads.append(ops.backward(g, x, P, dts, "euler", rows_out, sol, *gs))
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+def test_sol_info_pairing_is_checked(dev):
+    """ABI 220: the backward refuses a trajectory / keep pair that does not belong together"""
+    import torch
+    from gnode import ops, _lib
+    n, m, B = 600, 2400, 2
+    g, P, x = _setup(n, m, B, 3, dev)
+    dts = ops.step_sizes(ops.time_grid(6, 0.5))
+    gs = [torch.randn(len(dts) + 1, B * n, device=dev) for _ in range(3)]
+    S, I, R, sol_k = ops.forward(g, x, P, dts, "euler", None, want_sol=True, want_keep=True)
+    S, I, R, sol_n = ops.forward(g, x, P, dts, "euler", None, want_sol=True, want_keep=False)
+    keep = sol_k.gnode_keep
+    sol_k.gnode_keep = None
+    with pytest.raises(_lib.GnodeError):                    # kept trajectory, no buffer (python-side guard gone: the C ABI says no)
+        ops.backward(g, x, P, dts, "euler", None, sol_k, *gs, keep="auto")
+    with pytest.raises(_lib.GnodeError):                    # a keep buffer with a trajectory whose forward filled none
+        ops.backward(g, x, P, dts, "euler", None, sol_n, *gs, keep=keep)
+    sol_k.gnode_keep = keep
+    ops.backward(g, x, P, dts, "euler", None, sol_k, *gs)
+    ops.backward(g, x, P, dts, "euler", None, sol_n, *gs)
