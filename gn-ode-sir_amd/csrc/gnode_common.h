@@ -22,9 +22,14 @@ struct gnode_graph_s {
     int32_t* seg_lo;        // device [n_seg]: first CSR position of a segment
     int32_t* seg_hi;        // device [n_seg]: one past its last
     int32_t* hub_seg_ptr;   // device [n_hub+1]: segments of hub h are [ptr[h], ptr[h+1])
+    // persistent one-launch integration (gnode_pers64.hip): for 1 / 2 / 4 tiles per workgroup the node each lane-group slot
+    // owns, -1 for padding slots; null when the graph never takes that path
+    int32_t* persmap[3];
 };
 
 int gn_hub_build(gnode_graph_s* g, const int32_t* rowptr_host);
+int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host);     // the row maps above (gnode_pers64.hip)
+void gn_pers64_free(gnode_graph_s* g);
 void gn_hub_free(gnode_graph_s* g);
 // Hub sums of `ntables` (1 or 2) tables for a batch of B samples need this much of the CALLER's workspace (0 for a graph
 // without hub rows); gn_hub_gather carves its segment partials and hub sums from it: no allocation, no

@@ -585,8 +585,12 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
             return GNODE_ERR_HIP;
         }
     }
-    if (int e = gn_hub_build(g, rowptr_host)) {
+    for (int i = 0; i < 3; ++i) g->persmap[i] = nullptr;
+    int e_build = gn_hub_build(g, rowptr_host);
+    if (!e_build) e_build = gn_pers64_build(g, rowptr_host);
+    if (int e = e_build) {
         (void)hipFree(g->rowhdr);
+        gn_pers64_free(g);
         gn_hub_free(g);
         (void)hipFree(g->rowptr);
         (void)hipFree(g->col);
@@ -599,6 +603,7 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
 
 extern "C" int gnode_graph_destroy(gnode_graph_t g) {
     if (!g) return 0;
+    gn_pers64_free(g);
     gn_hub_free(g);
     (void)hipFree(g->rowptr);
     (void)hipFree(g->col);
@@ -864,6 +869,13 @@ extern "C" int gnode_forward_path(gnode_graph_t g, int64_t rows, int32_t H, int3
         if (plan_host) { plan_host[0] = pl.nt; plan_host[1] = pl.wgs; plan_host[2] = pl.span; plan_host[3] = pl.gpx; plan_host[4] = pl.concurrent; }
         return 2;
     }
+    return 0;
+}
+
+// diagnostic build (GN_PERS_PROF): per-phase 100 MHz ticks of the last persistent launch on this workspace
+extern "C" int gnode_forward_phase_ticks(int64_t rows, int32_t H, int32_t method, const void* workspace, uint64_t* ticks8_host) {
+    const PersCtl* ctl = (const PersCtl*)forward_ctl_ptr(const_cast<void*>(workspace), rows, H, method);
+    GN_HIP(hipMemcpy(ticks8_host, ctl->prof, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

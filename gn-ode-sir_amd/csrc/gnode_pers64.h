@@ -15,12 +15,13 @@ struct PersCtl {                       // device memory, zeroed by a memset node
     unsigned ticket[8][32];            // per XCC (a 128-B line each): the next free slot on that XCD
     unsigned error[32];                // [0] != 0: a workgroup gave up waiting (code), [1]: the epoch it waited for
     unsigned flags[PERS_FLAG_WORDS];   // per group `fstride` words: workgroup idx's last published epoch
+    unsigned long long prof[8];        // diagnostic build only (GN_PERS_PROF): 100 MHz ticks per phase, group 0 / workgroup 0
 };
 
 struct PersSched { float dt[128]; short slot[128]; int n_steps; };
 
 struct PersArgs {
-    const int* rowhdr; const int* col;
+    const int* rowhdr; const int* col; const int* rowmap;   // rowmap: lane-group slot -> node (or -1), per tile count (gnode_graph_s::persmap)
     int n, B; unsigned rows;
     int wgs, span, gpx, per, slots, n_xcc, rounds, concurrent, fstride;
     const float* Y0; const float* PR0; const float* beta; const float* gamma;

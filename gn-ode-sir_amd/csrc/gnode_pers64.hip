@@ -29,6 +29,7 @@
 #include "gnode_step64.h"
 #include "gnode_pers64.h"
 #include <algorithm>
+#include <vector>
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -46,47 +47,96 @@ template <int AUX> __device__ __forceinline__ void pers_st(rsrc_t rs, unsigned o
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), rs, off, 0, AUX);
 }
 
+// Diagnostic build (-DGN_PERS_PROF, tools/bench_persist.py --prof): thread 0 of every group's workgroup 0 sums the 100 MHz
+// clock between the phases of a step into ctl->prof (memory nothing else reads); in the product build no stamp executes.
+#ifdef GN_PERS_PROF
+#define PS_STAMP(I) { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); prof[I] += t_ - tp; tp = t_; } }
+#else
+#define PS_STAMP(I)
+#endif
+
 #define PS_ACC(V) acc.x += V.x; acc.y += V.y; acc.z += V.z; acc.w += V.w;
 
+// A neighbour slot the row does not have carries PS_OOB: the buffer load's range check answers 0 WITHOUT a memory access
+// (the per-step kernels point such slots at the table's zero row, which costs a real 256-B read each -- at 64 rows per CU
+// those reads were half of the texture-unit time of a step).  Adding +0 leaves a sum's bits alone.
+#define PS_OOB 0xFFFF0000u
+
+// N loads of consecutive neighbour slots K, K+1, ...: slot k is lane (k & 15)'s m[k >> 4] (a table byte offset)
+// 8 loads of consecutive neighbour slots K .. K+7: slot k is lane (k & 15)'s m[k >> 4] (a table byte offset)
+template <int K, int N, int NM>
+struct PsBatch {
+    static __device__ __forceinline__ void load(float4* v, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b) {
+        v[0] = pers_ld<16>(tab, (unsigned)row_bcast<K & 15>((int)m[K >> 4]) + lane_b);
+        PsBatch<K + 1, N - 1, NM>::load(v + 1, tab, m, lane_b);
+    }
+};
+template <int K, int NM>
+struct PsBatch<K, 0, NM> { static __device__ __forceinline__ void load(float4*, rsrc_t, const unsigned (&)[NM], unsigned) {} };
+
+// The first wave of loads: batches of 8 slots are issued as far as the longest of the wave's four rows needs (wave-uniform
+// tests: a load instruction costs the CU's texture unit 16 cycles whatever its lanes fetch, and with one workgroup per CU
+// that unit is what a step's gather waits for), at most DEPTH batches in flight; then `under()`, then the sums in slot order.
+template <int J, int DEPTH, int NM, class F>
+struct PsFirst {
+    static __device__ __forceinline__ void run(float4& acc, float4* v, int cnt, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b, F& under) {
+        PsBatch<8 * J, 8, NM>::load(v + 8 * J, tab, m, lane_b);
+        if constexpr (J + 1 < DEPTH) {
+            if (__any(cnt > 8 * (J + 1))) { PsFirst<J + 1, DEPTH, NM, F>::run(acc, v, cnt, tab, m, lane_b, under); return; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        under();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8 * (J + 1); ++k) { PS_ACC(v[k]) }
+    }
+};
+
+// batches J, J+1, ... NB-1 (8 slots each) of the register-held ids behind the first wave, each behind a wave-uniform test
+template <int J, int NB, int NM>
+struct PsRest {
+    static __device__ __forceinline__ void run(float4& acc, int cnt, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b) {
+        if (__any(cnt > 8 * J)) {
+            float4 u[8];
+            PsBatch<8 * J, 8, NM>::load(u, tab, m, lane_b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { PS_ACC(u[k]) }
+            PsRest<J + 1, NB, NM>::run(acc, cnt, tab, m, lane_b);
+        }
+    }
+};
+template <int NB, int NM>
+struct PsRest<NB, NB, NM> { static __device__ __forceinline__ void run(float4&, int, rsrc_t, const unsigned (&)[NM], unsigned) {} };
+
 // AI = sum of the row's neighbour rows of the table behind `tab`, ascending column order (the CPU scatter_add_ order of
-// the reference, ode_nn_ngraph_sim.py:73): 16 rows in flight per lane group; neighbour k < 16 is lane k's `m` (a byte
-// offset, or the table's zero row), 16 <= k < 32 lane (k-16)'s `m2`, beyond that the column list is walked.
-__device__ __forceinline__ float4 pers_gather(rsrc_t tab, const int* __restrict__ col, unsigned base, unsigned zoff, unsigned m,
-                                              unsigned m2, int start, int end, int sub, unsigned lane_b) {
+// the reference, ode_nn_ngraph_sim.py:73).  The first 16 NM neighbour ids live in registers (m), longer rows walk the
+// column list.  `under()` runs between the issue of the first wave of loads and its first use: independent work (the
+// previous step's read-out and streamed stores) travels under the gather's round trip.
+template <int NM, int DEPTH, class F>
+__device__ __forceinline__ float4 pers_gather(rsrc_t tab, const int* __restrict__ col, unsigned base, const unsigned (&m)[NM],
+                                              int start, int end, int sub, unsigned lane_b, F&& under) {
     float4 acc = zero4();
     const int cnt = end - start;
-#define PS_LD(K, M) pers_ld<16>(tab, (unsigned)row_bcast<(K) & 15>((int)(M)) + lane_b)
     {
-        const float4 v0 = PS_LD(0, m), v1 = PS_LD(1, m), v2 = PS_LD(2, m), v3 = PS_LD(3, m), v4 = PS_LD(4, m), v5 = PS_LD(5, m),
-                     v6 = PS_LD(6, m), v7 = PS_LD(7, m), v8 = PS_LD(8, m), v9 = PS_LD(9, m), v10 = PS_LD(10, m), v11 = PS_LD(11, m),
-                     v12 = PS_LD(12, m), v13 = PS_LD(13, m), v14 = PS_LD(14, m), v15 = PS_LD(15, m);
-        PS_ACC(v0) PS_ACC(v1) PS_ACC(v2) PS_ACC(v3) PS_ACC(v4) PS_ACC(v5) PS_ACC(v6) PS_ACC(v7)
-        PS_ACC(v8) PS_ACC(v9) PS_ACC(v10) PS_ACC(v11) PS_ACC(v12) PS_ACC(v13) PS_ACC(v14) PS_ACC(v15)
+        float4 v[8 * DEPTH];
+        PsFirst<0, DEPTH, NM, F>::run(acc, v, cnt, tab, m, lane_b, under);
     }
-    if (__any(cnt > 16)) {
-        const float4 v0 = PS_LD(0, m2), v1 = PS_LD(1, m2), v2 = PS_LD(2, m2), v3 = PS_LD(3, m2), v4 = PS_LD(4, m2), v5 = PS_LD(5, m2),
-                     v6 = PS_LD(6, m2), v7 = PS_LD(7, m2);
-        if (__any(cnt > 24)) {
-            const float4 v8 = PS_LD(8, m2), v9 = PS_LD(9, m2), v10 = PS_LD(10, m2), v11 = PS_LD(11, m2), v12 = PS_LD(12, m2),
-                         v13 = PS_LD(13, m2), v14 = PS_LD(14, m2), v15 = PS_LD(15, m2);
-            PS_ACC(v0) PS_ACC(v1) PS_ACC(v2) PS_ACC(v3) PS_ACC(v4) PS_ACC(v5) PS_ACC(v6) PS_ACC(v7)
-            PS_ACC(v8) PS_ACC(v9) PS_ACC(v10) PS_ACC(v11) PS_ACC(v12) PS_ACC(v13) PS_ACC(v14) PS_ACC(v15)
-        } else {
-            PS_ACC(v0) PS_ACC(v1) PS_ACC(v2) PS_ACC(v3) PS_ACC(v4) PS_ACC(v5) PS_ACC(v6) PS_ACC(v7)
-        }
-    }
-    if (__any(cnt > 32)) {
-        for (int e0 = start + 32; e0 < end; e0 += 16) {
+    PsRest<DEPTH, NM * 2, NM>::run(acc, cnt, tab, m, lane_b);
+    if (__any(cnt > NM * 16)) {
+        for (int e0 = start + NM * 16; e0 < end; e0 += 16) {
             const int c2 = end - e0;
-            const unsigned mm = (sub < c2) ? (base + (unsigned)col[e0 + sub]) * 256u : zoff;
-            const float4 v0 = PS_LD(0, mm), v1 = PS_LD(1, mm), v2 = PS_LD(2, mm), v3 = PS_LD(3, mm), v4 = PS_LD(4, mm), v5 = PS_LD(5, mm),
-                         v6 = PS_LD(6, mm), v7 = PS_LD(7, mm), v8 = PS_LD(8, mm), v9 = PS_LD(9, mm), v10 = PS_LD(10, mm), v11 = PS_LD(11, mm),
-                         v12 = PS_LD(12, mm), v13 = PS_LD(13, mm), v14 = PS_LD(14, mm), v15 = PS_LD(15, mm);
-            PS_ACC(v0) PS_ACC(v1) PS_ACC(v2) PS_ACC(v3) PS_ACC(v4) PS_ACC(v5) PS_ACC(v6) PS_ACC(v7)
-            PS_ACC(v8) PS_ACC(v9) PS_ACC(v10) PS_ACC(v11) PS_ACC(v12) PS_ACC(v13) PS_ACC(v14) PS_ACC(v15)
+            const unsigned mm[1] = {(sub < c2) ? (base + (unsigned)col[e0 + sub]) * 256u : PS_OOB};
+            float4 u[8];
+            PsBatch<0, 8, 1>::load(u, tab, mm, lane_b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { PS_ACC(u[k]) }
+            if (__any(c2 > 8)) {
+                PsBatch<8, 8, 1>::load(u, tab, mm, lane_b);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { PS_ACC(u[k]) }
+            }
         }
     }
-#undef PS_LD
     return acc;
 }
 
@@ -111,6 +161,12 @@ __device__ __forceinline__ bool pers_wait(unsigned* flags, int wgs, unsigned epo
 template <bool PRJ, int NT, bool SC1ST>
 __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
     constexpr int STAUX = SC1ST ? 16 : 0;
+    // registers: one workgroup per CU, so 256 / 512 / 1024 threads leave 512 / 256 / 128 VGPRs per lane
+    constexpr int NM = NT == 4 ? 2 : 4;                    // neighbour-id registers (16 ids each)
+#ifndef GN_PERS_DEPTH
+#define GN_PERS_DEPTH 4
+#endif
+    constexpr int DEPTH = NT == 4 ? 1 : GN_PERS_DEPTH;     // batches of 8 neighbour rows in flight per lane group
     constexpr int O_W = 0, O_W3 = O_W + 64 * TS, O_T = O_W3 + 256, TEAM_F = 4 * 16 * TS;
     extern __shared__ __attribute__((aligned(16))) float L[];
     __shared__ unsigned sh[4];
@@ -151,9 +207,14 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
     const unsigned tbytes = (rows + 1u) * 256u;
     const size_t slab = (size_t)rows * 64;
     const int n_steps = a.sched.n_steps;
-    const int node = idx * (16 * NT) + team * 16 + lr;
-    const bool valid = node < a.n;
+    // which node this lane group owns: the plan's row map deals degree-sorted quads of rows to the waves (a wave's four
+    // rows have similar lengths -- its load count is its longest row's) and the quads round-robin to the workgroups
+    const int node = a.rowmap[idx * (16 * NT) + team * 16 + lr];
+    const bool valid = node >= 0;
 
+#ifdef GN_PERS_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int round = 0; round < a.rounds; ++round) {
         const int b = round * a.concurrent + gl;
         if (b >= a.B) break;
@@ -163,15 +224,19 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
         const unsigned off = row * 256u + lane_b;
         // ---- the row's loop-invariant data: extent, neighbour ids (as table byte offsets), beta, gamma
         int start = 0, end = 0;
-        unsigned m = zoff, m2 = zoff;
+        unsigned m[NM];
+#pragma unroll
+        for (int j = 0; j < NM; ++j) m[j] = PS_OOB;
         if (valid) {
             const int* h = a.rowhdr + (size_t)node * 20;
             start = h[0]; end = h[1];
             const int d = end - start;
-            if (sub < d) m = (base + (unsigned)h[4 + sub]) * 256u;
-            if (16 + sub < d) m2 = (base + (unsigned)a.col[start + 16 + sub]) * 256u;
+            if (sub < d) m[0] = (base + (unsigned)h[4 + sub]) * 256u;
+#pragma unroll
+            for (int j = 1; j < NM; ++j)
+                if (16 * j + sub < d) m[j] = (base + (unsigned)a.col[start + 16 * j + sub]) * 256u;
         }
-        float4 ys = zero4(), yi = zero4(), yr = zero4(), pr = zero4(), zi = zero4(), zs;
+        float4 ys = zero4(), yi = zero4(), yr = zero4(), pr = zero4(), zi = zero4();
         float nb = 0.f, gm = 0.f;
         if (valid) {
             ys = ld4o(a.Y0, off); yi = ld4o(a.Y0 + slab, off);
@@ -183,11 +248,36 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
         __syncthreads();
         mfma_dual16<false, true>(TA, TB, Wslab, T2I, T2S, bias_l, fo, oo);       // Z_S(y_0)
         __syncthreads();
-        zs = *reinterpret_cast<const float4*>(T2S + ro);
+        float4 zs_k = zero4(), ai_k = zero4();             // step k-1's Z_S(y_{k-1}), A Z_I(y_{k-1}): stored one step late (training)
+
+        // outputs of step j (trajectory point j+1, kept activations of grid point j, read-out at grid point j+1): nothing in
+        // the launch consumes them, so they are issued UNDER the next step's gather (or after the last step)
+        auto outputs = [&](int j) {
+            if (!PRJ && valid) {
+                if (a.sol) {
+                    float* sn = a.sol + (size_t)(j + 1) * 4 * slab;
+                    st4so<true>(sn, off, ys); st4so<true>(sn + slab, off, yi); st4so<true>(sn + 2 * slab, off, yr);
+                    if (j >= 1) {
+                        if (a.keep) st4so<true>(gn_keep_ps(a.keep, rows, j), off, ai_k);
+                        else st4so<true>(a.sol + (size_t)j * 4 * slab + 3 * slab, off, ai_k);
+                    }
+                }
+                if (a.keep) st4so<true>(gn_keep_zs(a.keep, rows, j), off, zs_k);
+            }
+            const int slot = a.sched.slot[j];
+            if (slot >= 0) {
+                float pS, pI, pR;
+                const float prj[4] = {pr.x, pr.y, pr.z, pr.w};
+                readout64<PRJ>(ys, yi, yr, prj, sub, w3s, a.b3, a.w2, a.b2, pS, pI, pR);
+                if (valid && sub == 0) {
+                    const size_t o = (size_t)slot * rows + row;
+                    a.S[o] = pS; a.I[o] = pI; a.R[o] = pR;
+                }
+            }
+        };
 
         for (int k = 0; k < n_steps; ++k) {
             const float dt = a.sched.dt[k];
-            const int slot = a.sched.slot[k];
             float* const tab_cur = a.keep ? gn_keep_zi(a.keep, rows, k) : ((k & 1) ? a.Z1 : a.Z0);
             float* const tab_nxt = a.keep ? gn_keep_zi(a.keep, rows, k + 1) : ((k & 1) ? a.Z0 : a.Z1);
             if (k > 0) {
@@ -198,19 +288,23 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
                 __syncthreads();
                 if (sh[2] == 0u) return;
             }
-            // ---- gather + SIR update (ode_nn_ngraph_sim.py:75-77) + Euler step
-            const float4 acc = pers_gather(pers_rsrc(tab_cur, tbytes), a.col, base, zoff, m, m2, start, end, sub, lane_b);
+            PS_STAMP(0)
+            const float4 zs = *reinterpret_cast<const float4*>(T2S + ro);      // Z_S(y_k): the matrix phase behind the last flag
+            // ---- gather (step k-1's outputs under its round trip) + SIR update (ode_nn_ngraph_sim.py:75-77) + Euler step
+            const float4 acc = pers_gather<NM, DEPTH>(pers_rsrc(tab_cur, tbytes), a.col, base, m, start, end, sub, lane_b,
+                                                   [&]() { if (k > 0) outputs(k - 1); });
+            PS_STAMP(1)
             float4 dS, dI, dR;
             dS.x = nb * (acc.x * zs.x); dS.y = nb * (acc.y * zs.y); dS.z = nb * (acc.z * zs.z); dS.w = nb * (acc.w * zs.w);
             dR.x = gm * zi.x; dR.y = gm * zi.y; dR.z = gm * zi.z; dR.w = gm * zi.w;
             dI.x = -dS.x - dR.x; dI.y = -dS.y - dR.y; dI.z = -dS.z - dR.z; dI.w = -dS.w - dR.w;
             ys.x += dt * dS.x; ys.y += dt * dS.y; ys.z += dt * dS.z; ys.w += dt * dS.w;
             yi.x += dt * dI.x; yi.y += dt * dI.y; yi.z += dt * dI.z; yi.w += dt * dI.w;
-            float prj[4] = {0.f, 0.f, 0.f, 0.f};
             if (PRJ) {
                 float4 w3r[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w3r[q] = *reinterpret_cast<const float4*>(w3s + q * 64 + 4 * sub);
+                float prj[4];
                 prj[0] = pr.x + dt * (gm * row_sum16(fmaf(w3r[0].x, zi.x, fmaf(w3r[0].y, zi.y, fmaf(w3r[0].z, zi.z, w3r[0].w * zi.w)))));
                 prj[1] = pr.y + dt * (gm * row_sum16(fmaf(w3r[1].x, zi.x, fmaf(w3r[1].y, zi.y, fmaf(w3r[1].z, zi.z, w3r[1].w * zi.w)))));
                 prj[2] = pr.z + dt * (gm * row_sum16(fmaf(w3r[2].x, zi.x, fmaf(w3r[2].y, zi.y, fmaf(w3r[2].z, zi.z, w3r[2].w * zi.w)))));
@@ -218,19 +312,21 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
                 pr = make_float4(prj[0], prj[1], prj[2], prj[3]);
             } else {
                 yr.x += dt * dR.x; yr.y += dt * dR.y; yr.z += dt * dR.z; yr.w += dt * dR.w;
+                // kept for the backward: Z_S(y_k) and A Z_I(y_k) [* Z_S (1 - Z_S) with a keep buffer]
+                zs_k = zs;
+                ai_k = acc;
+                if (a.keep) ai_k = make_float4(acc.x * (zs.x * (1.0f - zs.x)), acc.y * (zs.y * (1.0f - zs.y)),
+                                               acc.z * (zs.z * (1.0f - zs.z)), acc.w * (zs.w * (1.0f - zs.w)));
             }
-            // kept for the backward (training): Z_S(y_k) and A Z_I(y_k) [* Z_S (1 - Z_S) with a keep buffer]; stored after the flag
-            const float4 zs_k = zs;
-            float4 ai_k = acc;
-            if (!PRJ && a.keep) ai_k = make_float4(acc.x * (zs.x * (1.0f - zs.x)), acc.y * (zs.y * (1.0f - zs.y)),
-                                                   acc.z * (zs.z * (1.0f - zs.z)), acc.w * (zs.w * (1.0f - zs.w)));
             *reinterpret_cast<float4*>(TA + ro) = yi;
             *reinterpret_cast<float4*>(TB + ro) = ys;
             __syncthreads();
-            mfma_dual16<true, true>(TA, TB, Wslab, T2I, T2S, bias_l, fo, oo);    // Z_I(y_{k+1}), Z_S(y_{k+1})
+            PS_STAMP(2)
+            // only Z_I(y_{k+1}) is on the way to the flag; Z_S(y_{k+1}) follows behind it (same chains either way)
+            mfma_dual16<true, false>(TA, TB, Wslab, T2I, T2S, bias_l, fo, oo);
             __syncthreads();
+            PS_STAMP(3)
             zi = *reinterpret_cast<const float4*>(T2I + ro);
-            zs = *reinterpret_cast<const float4*>(T2S + ro);
             const bool last = k + 1 == n_steps;
             if (!last || a.keep) {
                 const rsrc_t tn = pers_rsrc(tab_nxt, tbytes);
@@ -241,36 +337,52 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains, then the barrier, then ONE flag
                 __syncthreads();
                 if (threadIdx.x == 0) __hip_atomic_store(flags + idx, ebase + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            // ---- under the barrier's latency: trajectory point, kept activations, read-out head
-            if (!PRJ && valid) {
-                if (a.sol) {
-                    float* sn = a.sol + (size_t)(k + 1) * 4 * slab;
-                    st4so<true>(sn, off, ys); st4so<true>(sn + slab, off, yi); st4so<true>(sn + 2 * slab, off, yr);
-                    if (k >= 1) {
-                        if (a.keep) st4so<true>(gn_keep_ps(a.keep, rows, k), off, ai_k);
-                        else st4so<true>(a.sol + (size_t)k * 4 * slab + 3 * slab, off, ai_k);
-                    }
-                }
-                if (a.keep) st4so<true>(gn_keep_zs(a.keep, rows, k), off, zs_k);
-            }
-            if (slot >= 0) {
-                float pS, pI, pR;
-                readout64<PRJ>(ys, yi, yr, prj, sub, w3s, a.b3, a.w2, a.b2, pS, pI, pR);
-                if (valid && sub == 0) {
-                    const size_t o = (size_t)slot * rows + row;
-                    a.S[o] = pS; a.I[o] = pI; a.R[o] = pR;
-                }
+                PS_STAMP(4)
+                mfma_dual16<false, true>(TA, TB, Wslab, T2I, T2S, bias_l, fo, oo);   // Z_S(y_{k+1}), read behind the next barrier
+                PS_STAMP(5)
             }
         }
+        outputs(n_steps - 1);
         __syncthreads();                                    // the operand tiles are restaged by the next round
     }
+#ifdef GN_PERS_PROF
+    if (threadIdx.x == 0 && idx == 0 && gl == 0) for (int i = 0; i < 8; ++i) a.ctl->prof[i] = prof[i];
+#endif
 }
 #undef PS_ACC
 
-// --------------------------------------------------------------------------- host: plan + launch
+// --------------------------------------------------------------------------- host: row maps, plan, launch
+// Slot s of the map for nt tiles per workgroup = lane group (s % (16 nt)) of workgroup s / (16 nt).  Rows are sorted by
+// length (longest first, ties by id) and cut into quads; quad q goes to wave position q / wgs of workgroup q % wgs: the four
+// rows of a wave have neighbouring lengths, and every workgroup gets quads from the whole length spectrum (equal bytes per CU).
+static const int kPersMaxRows = 256 * 64;              // one resident grid: 256 workgroups x 64 rows
+int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host) {
+    for (int i = 0; i < 3; ++i) g->persmap[i] = nullptr;
+    if (g->n > kPersMaxRows || g->n_hub > 0) return 0;
+    std::vector<int32_t> order((size_t)g->n);
+    for (int32_t r = 0; r < g->n; ++r) order[r] = r;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        return rowptr_host[x + 1] - rowptr_host[x] > rowptr_host[y + 1] - rowptr_host[y]; });
+    for (int i = 0; i < 3; ++i) {
+        const int nt = 1 << i, per_wg = 16 * nt, wgs = (g->n + per_wg - 1) / per_wg, quads_per_wg = 4 * nt;
+        std::vector<int32_t> map((size_t)wgs * per_wg, -1);
+        const int nq = (g->n + 3) / 4;
+        for (int q = 0; q < nq; ++q) {
+            const int wg = q % wgs, pos = q / wgs;          // pos < quads_per_wg because nq <= wgs * quads_per_wg
+            if (pos >= quads_per_wg) return GNODE_ERR_ARG;
+            for (int j = 0; j < 4 && 4 * q + j < g->n; ++j) map[(size_t)wg * per_wg + 4 * pos + j] = order[4 * q + j];
+        }
+        GN_HIP(hipMalloc(&g->persmap[i], sizeof(int32_t) * map.size()));
+        GN_HIP(hipMemcpy(g->persmap[i], map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+void gn_pers64_free(gnode_graph_s* g) {
+    for (int i = 0; i < 3; ++i) if (g->persmap[i]) { (void)hipFree(g->persmap[i]); g->persmap[i] = nullptr; }
+}
+
 bool gn_pers64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p) {
-    if (n_steps < 1 || n_steps > 128 || B < 1 || g->n_hub > 0) return false;
+    if (n_steps < 1 || n_steps > 128 || B < 1 || g->n_hub > 0 || !g->persmap[0]) return false;
     const int n_xcc = 8;
     if (g->num_cu < 64 || g->num_cu % n_xcc) return false;
     const int slots = g->num_cu / n_xcc;
@@ -316,7 +428,7 @@ int gn_launch_pers64(const gnode_graph_s* g, const PersPlan& pl, long rows, cons
                      const int* slot_host, int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol, float* keep,
                      void* ctl, hipStream_t st) {
     PersArgs a;
-    a.rowhdr = g->rowhdr; a.col = g->col; a.n = g->n; a.B = (int)(rows / g->n); a.rows = (unsigned)rows;
+    a.rowhdr = g->rowhdr; a.col = g->col; a.rowmap = g->persmap[pl.nt == 1 ? 0 : pl.nt == 2 ? 1 : 2]; a.n = g->n; a.B = (int)(rows / g->n); a.rows = (unsigned)rows;
     a.wgs = pl.wgs; a.span = pl.span; a.gpx = pl.gpx; a.per = pl.per; a.slots = pl.slots; a.n_xcc = pl.n_xcc;
     a.rounds = pl.rounds; a.concurrent = pl.concurrent; a.fstride = pl.fstride;
     a.Y0 = Y0; a.PR0 = PR0; a.beta = beta; a.gamma = gamma; a.Z0 = Z0; a.Z1 = Z1; a.keep = keep;
