@@ -144,12 +144,24 @@ __device__ __forceinline__ float4 pers_gather(rsrc_t tab, const int* __restrict_
 // Returns false on the give-up path (the caller leaves the kernel).  Callers follow it with __syncthreads().
 __device__ __forceinline__ bool pers_wait(unsigned* flags, int wgs, unsigned epoch, unsigned* err, int lane) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    // a poll is one fabric round trip; three sweeps stay in flight a third of a round trip apart, so the last flag is seen
+    // one round trip after it lands instead of up to two
+    // (a lane's words of one sweep are loaded before any is compared: the compares of sweep 0 come after sweep 2's loads)
+    auto sweep = [&](unsigned (&f)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = (lane + 64 * q < wgs) ? __hip_atomic_load(flags + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+    };
+    auto all_ge = [&](const unsigned (&f)[4]) { return min(min(f[0], f[1]), min(f[2], f[3])) >= epoch; };
     for (;;) {
-        bool ok = true;
-        for (int j = lane; j < wgs; j += 64)
-            ok &= __hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
-        if (__all(ok)) return true;
-        __builtin_amdgcn_s_sleep(1);
+#ifndef GN_PERS_POLL3
+#define GN_PERS_POLL3 0
+#endif
+        unsigned f0[4], f1[4], f2[4];
+        sweep(f0);
+        if (GN_PERS_POLL3) { __builtin_amdgcn_s_sleep(3); sweep(f1); __builtin_amdgcn_s_sleep(3); sweep(f2); }
+        else __builtin_amdgcn_s_sleep(1);
+        const bool o0 = all_ge(f0), o1 = GN_PERS_POLL3 && all_ge(f1), o2 = GN_PERS_POLL3 && all_ge(f2);
+        if (__all(o0) || __all(o1) || __all(o2)) return true;
         if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {        // 2 s at 100 MHz
             if (lane == 0) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                              __hip_atomic_store(err + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
             *reinterpret_cast<float4*>(TB + ro) = ys;
             __syncthreads();
             PS_STAMP(2)
-            // only Z_I(y_{k+1}) is on the way to the flag; Z_S(y_{k+1}) follows behind it (same chains either way)
+            // only Z_I(y_{k+1}) is on the way to the row store; Z_S(y_{k+1}) follows behind it (same chains either way)
             mfma_dual16<true, false>(TA, TB, Wslab, T2I, T2S, bias_l, fo, oo);
             __syncthreads();
             PS_STAMP(3)
@@ -338,7 +350,9 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
                 __syncthreads();
                 if (threadIdx.x == 0) __hip_atomic_store(flags + idx, ebase + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 PS_STAMP(4)
-                mfma_dual16<false, true>(TA, TB, Wslab, T2I, T2S, bias_l, fo, oo);   // Z_S(y_{k+1}), read behind the next barrier
+                // Z_S(y_{k+1}) is read behind the next barrier: its matrix phase runs under the flag's flight (measured: in
+                // FRONT of the flag it delays every workgroup of the group by its full length)
+                mfma_dual16<false, true>(TA, TB, Wslab, T2I, T2S, bias_l, fo, oo);
                 PS_STAMP(5)
             }
         }

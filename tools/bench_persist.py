@@ -46,8 +46,9 @@ def main():
             path, plan = ops.forward_path(g, B * n, 64, len(dts))
             ws = torch.empty(ops._lib.load().gnode_forward_workspace_bytes(g.handle, B * n, 64, 0), dtype=torch.uint8, device=dev)
             out = {"case": name, "n": n, "B": B, "steps": len(dts), "path": path, "plan(nt,wgs,span,gpx,conc)": plan}
+            emit = np.asarray([len(dts)], dtype=np.int32) if "--last-only" in sys.argv else None     # read-out at the last grid point only
             for persist in (False, True):
-                t = ev_time(lambda: ops.forward(g, x, P, dts, "euler", None, workspace=ws, persist=persist))
+                t = ev_time(lambda: ops.forward(g, x, P, dts, "euler", emit, workspace=ws, persist=persist))
                 tt = ev_time(lambda: ops.forward(g, x, P, dts, "euler", rows_out, want_sol=True, workspace=ws, persist=persist), 10)
                 key = "persist" if persist else "per_step"
                 out[key + "_fwd_ms"] = round(t, 4)
@@ -56,7 +57,7 @@ def main():
                 assert ops.forward_status() == 0
                 if persist and path == 2 and "--prof" in sys.argv:          # library built with GNODE_EXTRA_FLAGS=-DGN_PERS_PROF
                     import ctypes as C
-                    ops.forward(g, x, P, dts, "euler", None, workspace=ws, persist=True)
+                    ops.forward(g, x, P, dts, "euler", emit, workspace=ws, persist=True)
                     torch.cuda.synchronize()
                     tk = (C.c_uint64 * 8)()
                     ops._lib.load().gnode_forward_phase_ticks(C.c_int64(B * n), 64, 0, C.c_void_p(ws.data_ptr()), tk)
