@@ -28,6 +28,7 @@
 #include "gnode_gather.h"
 #include "gnode_mfma64.h"
 #include "gnode_head64.h"
+#include "gnode_pers64.h"
 #include <algorithm>
 
 __device__ __forceinline__ float4 ld4b(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -1124,8 +1125,10 @@ static size_t backward_fixed_bytes(int64_t rows, int32_t H) {
     const PartLayout L{H};
     const size_t slab = bwd_slab_bytes(rows, H);
     // a[3], Z[2], q[1], dpre[2] slabs + beta, gamma + partial buffer + reduced gradient vector
+    // (+ the control block of the persistent sweep, gnode_pers64_bwd.hip)
     return 8 * slab + 2 * gn_align((size_t)rows * sizeof(float)) +
-           gn_align((size_t)BWD_NWG * L.total() * sizeof(float)) + gn_align((size_t)L.total() * sizeof(float));
+           gn_align((size_t)BWD_NWG * L.total() * sizeof(float)) + gn_align((size_t)L.total() * sizeof(float)) +
+           (H == 64 ? gn_pers64_ctl_bytes() : 0);
 }
 
 extern "C" size_t gnode_backward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H) {
@@ -1143,7 +1146,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                                   int32_t n_steps, const int32_t* out_rows_host, int32_t n_out, const float* sol,
                                   const float* keep, size_t keep_bytes, const float* gS, const float* gI, const float* gR,
                                   const gnode_params* grads, int64_t rows, int32_t H, void* workspace,
-                                  size_t workspace_bytes, void* stream, int32_t sol_info) {
+                                  size_t workspace_bytes, void* stream, int32_t flags, int32_t sol_info) {
     GN_CHECK_ARG(g && x && p && sol && gS && gI && gR && grads && workspace, "gnode_backward_f32: null pointer");
     GN_CHECK_ARG(n_steps >= 0 && (n_steps == 0 || dt_host), "gnode_backward_f32: bad n_steps/dt");
     GN_CHECK_ARG(H >= 4 && H <= 128 && H % 4 == 0, "gnode_backward_f32: need 4 <= H <= 128, H %% 4 == 0 (got %d)", H);
@@ -1246,7 +1249,23 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         const long total = (long)(rows / g->n) * tps;
         const int grid = (int)std::min<long>(std::min<long>((long)GN_BWD_RPG1_OCC * g->num_cu, BWD_NWG), total);
         slots_used = std::max(slots_used, grid);
+        // mid-size graphs: intervals G-2 .. 1 over the kept activations in ONE persistent launch (gnode_pers64_bwd.hip)
+        PersPlan pplan;
+        const bool persist = keep && G >= 3 && !(flags & GNODE_FWD_PER_STEP) && gn_pers_bwd64_plan(g, rows / g->n, n_steps, &pplan);
         for (int i = G - 1; i >= 1; --i) {
+            if (persist && i == G - 2) {
+                int slot_prev[128];
+                for (int j = 1; j <= G - 2; ++j) slot_prev[j] = slot_of(j - 1);
+                int pslots = 0;
+                const bool sampled = gn_prof_begin(2, st);
+                if (int e = gn_launch_pers_bwd64(g, pplan, rows, G, Qb[0], Qb[1], sol, keep, p->odefunc_linear_weight, beta, gamma, a, part,
+                                                 gS, gI, gR, p, dt_host, slot_prev,
+                                                 ws + backward_fixed_bytes(rows, H) - gn_pers64_ctl_bytes(), &pslots, st))
+                    return e;
+                if (sampled) gn_prof_end(2, st);
+                slots_used = std::max(slots_used, pslots);
+                break;
+            }
             const int cur = (G - 1 - i) & 1;
             const bool two = !ai_saved || i == G - 1;          // A Z_I(y_{G-1}) was never needed by the forward
             const float *AIhub = nullptr, *GQhub = nullptr;

@@ -519,6 +519,7 @@ int gn_device_setup_once(int dev) {
     if (int e = gn_ode_set_attributes()) return e;
     if (int e = gn_h64_set_attributes()) return e;
     if (int e = gn_pers64_set_attributes()) return e;
+    if (int e = gn_pers_bwd64_set_attributes()) return e;
     if (int e = gn_h128_set_attributes()) return e;
     if (int e = gn_bwd_set_attributes()) return e;
     if (int e = gn_bwd_tiny_set_attributes()) return e;

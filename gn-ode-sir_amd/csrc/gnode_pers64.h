@@ -18,12 +18,19 @@ struct PersCtl {                       // device memory, zeroed by a memset node
     unsigned long long prof[8];        // diagnostic build only (GN_PERS_PROF): 100 MHz ticks per phase, group 0 / workgroup 0
 };
 
+// the part of the plan a workgroup needs to find its place
+struct PersPlace { int wgs, span, gpx, per, slots, n_xcc, rounds, concurrent, fstride; };
+static inline PersPlace pers_place_of(const PersPlan& pl) {
+    PersPlace q; q.wgs = pl.wgs; q.span = pl.span; q.gpx = pl.gpx; q.per = pl.per; q.slots = pl.slots; q.n_xcc = pl.n_xcc;
+    q.rounds = pl.rounds; q.concurrent = pl.concurrent; q.fstride = pl.fstride; return q;
+}
+
 struct PersSched { float dt[128]; short slot[128]; int n_steps; };
 
 struct PersArgs {
     const int* rowhdr; const int* col; const int* rowmap;   // rowmap: lane-group slot -> node (or -1), per tile count (gnode_graph_s::persmap)
     int n, B; unsigned rows;
-    int wgs, span, gpx, per, slots, n_xcc, rounds, concurrent, fstride;
+    PersPlace pp;
     const float* Y0; const float* PR0; const float* beta; const float* gamma;
     float* Z0; float* Z1; float* keep;
     const float* W; const float* bias; const float* w3; const float* b3; const float* w2; const float* b2;
@@ -41,3 +48,11 @@ int gn_launch_pers64(const gnode_graph_s* g, const PersPlan& pl, long rows, cons
                      const float* W, const float* bias, const float* beta, const float* gamma, const float* dt_host,
                      const int* slot_host, int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol, float* keep,
                      void* ctl, hipStream_t st);
+
+// adjoint sweep, intervals G-2 .. 1, in one persistent launch (gnode_pers64_bwd.hip)
+int gn_pers_bwd64_set_attributes();
+bool gn_pers_bwd64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p);
+int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, int G, float* Q0, float* Q1, const float* sol,
+                         const float* keep, const float* W, const float* beta, const float* gamma, float* a, float* part,
+                         const float* gS, const float* gI, const float* gR, const gnode_params* p, const float* dt_host,
+                         const int* slot_of_prev, void* ctl, int* slots, hipStream_t st);

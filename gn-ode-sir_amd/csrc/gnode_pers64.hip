@@ -28,147 +28,9 @@
 #include "gnode_mfma64.h"
 #include "gnode_step64.h"
 #include "gnode_pers64.h"
+#include "gnode_pers64_dev.h"
 #include <algorithm>
 #include <vector>
-
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ rsrc_t pers_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
-}
-// AUX 16 = sc1 (agent-coherent: bypasses this CU's L1 / writes through), 0 = plain
-template <int AUX> __device__ __forceinline__ float4 pers_ld(rsrc_t rs, unsigned off) {
-    const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-template <int AUX> __device__ __forceinline__ void pers_st(rsrc_t rs, unsigned off, float4 v) {
-    const v4f t = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), rs, off, 0, AUX);
-}
-
-// Diagnostic build (-DGN_PERS_PROF, tools/bench_persist.py --prof): thread 0 of every group's workgroup 0 sums the 100 MHz
-// clock between the phases of a step into ctl->prof (memory nothing else reads); in the product build no stamp executes.
-#ifdef GN_PERS_PROF
-#define PS_STAMP(I) { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); prof[I] += t_ - tp; tp = t_; } }
-#else
-#define PS_STAMP(I)
-#endif
-
-#define PS_ACC(V) acc.x += V.x; acc.y += V.y; acc.z += V.z; acc.w += V.w;
-
-// A neighbour slot the row does not have carries PS_OOB: the buffer load's range check answers 0 WITHOUT a memory access
-// (the per-step kernels point such slots at the table's zero row, which costs a real 256-B read each -- at 64 rows per CU
-// those reads were half of the texture-unit time of a step).  Adding +0 leaves a sum's bits alone.
-#define PS_OOB 0xFFFF0000u
-
-// N loads of consecutive neighbour slots K, K+1, ...: slot k is lane (k & 15)'s m[k >> 4] (a table byte offset)
-// 8 loads of consecutive neighbour slots K .. K+7: slot k is lane (k & 15)'s m[k >> 4] (a table byte offset)
-template <int K, int N, int NM>
-struct PsBatch {
-    static __device__ __forceinline__ void load(float4* v, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b) {
-        v[0] = pers_ld<16>(tab, (unsigned)row_bcast<K & 15>((int)m[K >> 4]) + lane_b);
-        PsBatch<K + 1, N - 1, NM>::load(v + 1, tab, m, lane_b);
-    }
-};
-template <int K, int NM>
-struct PsBatch<K, 0, NM> { static __device__ __forceinline__ void load(float4*, rsrc_t, const unsigned (&)[NM], unsigned) {} };
-
-// The first wave of loads: batches of 8 slots are issued as far as the longest of the wave's four rows needs (wave-uniform
-// tests: a load instruction costs the CU's texture unit 16 cycles whatever its lanes fetch, and with one workgroup per CU
-// that unit is what a step's gather waits for), at most DEPTH batches in flight; then `under()`, then the sums in slot order.
-template <int J, int DEPTH, int NM, class F>
-struct PsFirst {
-    static __device__ __forceinline__ void run(float4& acc, float4* v, int cnt, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b, F& under) {
-        PsBatch<8 * J, 8, NM>::load(v + 8 * J, tab, m, lane_b);
-        if constexpr (J + 1 < DEPTH) {
-            if (__any(cnt > 8 * (J + 1))) { PsFirst<J + 1, DEPTH, NM, F>::run(acc, v, cnt, tab, m, lane_b, under); return; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        under();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 8 * (J + 1); ++k) { PS_ACC(v[k]) }
-    }
-};
-
-// batches J, J+1, ... NB-1 (8 slots each) of the register-held ids behind the first wave, each behind a wave-uniform test
-template <int J, int NB, int NM>
-struct PsRest {
-    static __device__ __forceinline__ void run(float4& acc, int cnt, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b) {
-        if (__any(cnt > 8 * J)) {
-            float4 u[8];
-            PsBatch<8 * J, 8, NM>::load(u, tab, m, lane_b);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { PS_ACC(u[k]) }
-            PsRest<J + 1, NB, NM>::run(acc, cnt, tab, m, lane_b);
-        }
-    }
-};
-template <int NB, int NM>
-struct PsRest<NB, NB, NM> { static __device__ __forceinline__ void run(float4&, int, rsrc_t, const unsigned (&)[NM], unsigned) {} };
-
-// AI = sum of the row's neighbour rows of the table behind `tab`, ascending column order (the CPU scatter_add_ order of
-// the reference, ode_nn_ngraph_sim.py:73).  The first 16 NM neighbour ids live in registers (m), longer rows walk the
-// column list.  `under()` runs between the issue of the first wave of loads and its first use: independent work (the
-// previous step's read-out and streamed stores) travels under the gather's round trip.
-template <int NM, int DEPTH, class F>
-__device__ __forceinline__ float4 pers_gather(rsrc_t tab, const int* __restrict__ col, unsigned base, const unsigned (&m)[NM],
-                                              int start, int end, int sub, unsigned lane_b, F&& under) {
-    float4 acc = zero4();
-    const int cnt = end - start;
-    {
-        float4 v[8 * DEPTH];
-        PsFirst<0, DEPTH, NM, F>::run(acc, v, cnt, tab, m, lane_b, under);
-    }
-    PsRest<DEPTH, NM * 2, NM>::run(acc, cnt, tab, m, lane_b);
-    if (__any(cnt > NM * 16)) {
-        for (int e0 = start + NM * 16; e0 < end; e0 += 16) {
-            const int c2 = end - e0;
-            const unsigned mm[1] = {(sub < c2) ? (base + (unsigned)col[e0 + sub]) * 256u : PS_OOB};
-            float4 u[8];
-            PsBatch<0, 8, 1>::load(u, tab, mm, lane_b);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { PS_ACC(u[k]) }
-            if (__any(c2 > 8)) {
-                PsBatch<8, 8, 1>::load(u, tab, mm, lane_b);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { PS_ACC(u[k]) }
-            }
-        }
-    }
-    return acc;
-}
-
-// Wave 0 of the workgroup waits until every workgroup of the group has published `epoch` (flags only grow inside a launch).
-// Returns false on the give-up path (the caller leaves the kernel).  Callers follow it with __syncthreads().
-__device__ __forceinline__ bool pers_wait(unsigned* flags, int wgs, unsigned epoch, unsigned* err, int lane) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    // a poll is one fabric round trip; three sweeps stay in flight a third of a round trip apart, so the last flag is seen
-    // one round trip after it lands instead of up to two
-    // (a lane's words of one sweep are loaded before any is compared: the compares of sweep 0 come after sweep 2's loads)
-    auto sweep = [&](unsigned (&f)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f[q] = (lane + 64 * q < wgs) ? __hip_atomic_load(flags + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
-    };
-    auto all_ge = [&](const unsigned (&f)[4]) { return min(min(f[0], f[1]), min(f[2], f[3])) >= epoch; };
-    for (;;) {
-#ifndef GN_PERS_POLL3
-#define GN_PERS_POLL3 0
-#endif
-        unsigned f0[4], f1[4], f2[4];
-        sweep(f0);
-        if (GN_PERS_POLL3) { __builtin_amdgcn_s_sleep(3); sweep(f1); __builtin_amdgcn_s_sleep(3); sweep(f2); }
-        else __builtin_amdgcn_s_sleep(1);
-        const bool o0 = all_ge(f0), o1 = GN_PERS_POLL3 && all_ge(f1), o2 = GN_PERS_POLL3 && all_ge(f2);
-        if (__all(o0) || __all(o1) || __all(o2)) return true;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {        // 2 s at 100 MHz
-            if (lane == 0) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                             __hip_atomic_store(err + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            return false;
-        }
-    }
-}
 
 template <bool PRJ, int NT, bool SC1ST>
 __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
@@ -184,22 +46,11 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
     __shared__ unsigned sh[4];
     const int team = threadIdx.x >> 8, tid = threadIdx.x & 255;
     const int lane = tid & 63, w = tid >> 6, g = lane >> 4, sub = lane & 15;
-    if (threadIdx.x == 0) {
-        const unsigned xcc = ((unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11))) % (unsigned)a.n_xcc;   // HW_REG_XCC_ID
-        sh[0] = xcc;
-        sh[1] = atomicAdd(&a.ctl->ticket[xcc][0], 1u);
-        sh[2] = 1u;
-    }
     if (team == 0) load_W_to_lds<false>(a.W, L + O_W);
     if (threadIdx.x < 256) L[O_W3 + threadIdx.x] = a.w3[threadIdx.x];
-    __syncthreads();
-    const int xcc = (int)sh[0], tk = (int)sh[1];
     int gl, idx;                                           // concurrent group, workgroup inside the group
-    bool active;
-    if (a.span == 1) { const int gi = tk / a.wgs; idx = tk - gi * a.wgs; gl = gi * a.n_xcc + xcc; active = tk < a.slots && gi < a.gpx; }
-    else { gl = xcc / a.span; idx = (xcc % a.span) * a.per + tk; active = tk < a.per && idx < a.wgs; }
-    if (!active) return;
-    unsigned* const flags = a.ctl->flags + (size_t)gl * a.fstride;
+    if (!pers_place(a.pp, a.ctl, sh, gl, idx)) return;
+    unsigned* const flags = a.ctl->flags + (size_t)gl * a.pp.fstride;
     unsigned* const err = a.ctl->error;
 
     const float bias_l = a.bias[16 * w + (lane & 15)];
@@ -227,8 +78,8 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
 #ifdef GN_PERS_PROF
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (int round = 0; round < a.rounds; ++round) {
-        const int b = round * a.concurrent + gl;
+    for (int round = 0; round < a.pp.rounds; ++round) {
+        const int b = round * a.pp.concurrent + gl;
         if (b >= a.B) break;
         const unsigned ebase = (unsigned)round * (unsigned)n_steps;
         const unsigned base = (unsigned)b * (unsigned)a.n;
@@ -295,7 +146,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
             if (k > 0) {
                 // table k is complete once every workgroup of the group has published epoch k
                 bool ok = true;
-                if (threadIdx.x < 64) ok = pers_wait(flags, a.wgs, ebase + (unsigned)k, err, lane);
+                if (threadIdx.x < 64) ok = pers_wait(flags, a.pp.wgs, ebase + (unsigned)k, err, lane);
                 if (threadIdx.x < 64 && !ok) sh[2] = 0u;
                 __syncthreads();
                 if (sh[2] == 0u) return;
@@ -443,8 +294,7 @@ int gn_launch_pers64(const gnode_graph_s* g, const PersPlan& pl, long rows, cons
                      void* ctl, hipStream_t st) {
     PersArgs a;
     a.rowhdr = g->rowhdr; a.col = g->col; a.rowmap = g->persmap[pl.nt == 1 ? 0 : pl.nt == 2 ? 1 : 2]; a.n = g->n; a.B = (int)(rows / g->n); a.rows = (unsigned)rows;
-    a.wgs = pl.wgs; a.span = pl.span; a.gpx = pl.gpx; a.per = pl.per; a.slots = pl.slots; a.n_xcc = pl.n_xcc;
-    a.rounds = pl.rounds; a.concurrent = pl.concurrent; a.fstride = pl.fstride;
+    a.pp = pers_place_of(pl);
     a.Y0 = Y0; a.PR0 = PR0; a.beta = beta; a.gamma = gamma; a.Z0 = Z0; a.Z1 = Z1; a.keep = keep;
     a.W = W; a.bias = bias; a.w3 = p->linear3_weight; a.b3 = p->linear3_bias; a.w2 = p->linearS2_weight; a.b2 = p->linearS2_bias;
     a.S = S; a.I = I; a.R = R; a.sol = sol; a.ctl = (PersCtl*)ctl;

@@ -90,7 +90,7 @@ def load():
     lib.gnode_backward_workspace_bytes.argtypes = [vp, i64, i32]
     lib.gnode_backward_workspace_bytes.restype = sz
     lib.gnode_backward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, vp, i32, vp, vp, sz, vp, vp, vp,
-                                       C.POINTER(Params), i64, i32, vp, sz, vp, i32]
+                                       C.POINTER(Params), i64, i32, vp, sz, vp, i32, i32]
     lib.gnode_backward_f32.restype = C.c_int
     lib.gnode_sir_workspace_bytes.argtypes = [vp, i32]
     lib.gnode_sir_workspace_bytes.restype = sz

@@ -149,7 +149,7 @@ def forward_status() -> int:
 
 
 def backward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray, method: str, out_rows, sol: torch.Tensor,
-             gS: torch.Tensor, gI: torch.Tensor, gR: torch.Tensor, keep="auto") -> dict:
+             gS: torch.Tensor, gI: torch.Tensor, gR: torch.Tensor, keep="auto", persist: bool | None = None) -> dict:
     """Adjoint-Euler parameter gradients (torchdiffeq odeint_adjoint semantics)
     given the saved trajectory `sol` and the upstream gradients of S, I, R ([n_out, rows]).
     keep: the forward's kept activations ("auto": ``sol.gnode_keep`` when `forward` attached it; None: recompute)."""
@@ -181,7 +181,8 @@ def backward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarra
         _lib.host_ptr(out_rows) if out_rows is not None else None, n_out, _lib.ptr(_f32c(sol)),
         _lib.ptr(keep) if keep is not None else None, keep.numel() * 4 if keep is not None else 0,
         _lib.ptr(_f32c(gS)), _lib.ptr(_f32c(gI)), _lib.ptr(_f32c(gR)), C.byref(gp), rows, H,
-        _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), int(getattr(sol, "gnode_info", -1))))
+        _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), 0 if (PERSIST_DEFAULT if persist is None else persist) else FWD_PER_STEP,
+        int(getattr(sol, "gnode_info", -1))))
     return grads
 
 

@@ -174,6 +174,8 @@ int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_params* p, co
  *                but the last reads the kept activations; gradients agree with the
  *                recomputing path to fp32 rounding of the summation order), or NULL for a
  *                trajectory that was produced without one
+ *   flags        0, or GNODE_FWD_PER_STEP: one launch per interval even where the persistent sweep applies (mid-size
+ *                graphs at H = 64 with a keep buffer: intervals n_steps-1 .. 1 run as ONE launch, see the forward)
  *   sol_info     what gnode_forward_f32 reported through sol_info_host for that call (checked against
  *                `keep`: GNODE_ERR_ARG on a mismatch), or -1 = unchecked (the caller vouches for the pairing)
  *   gS, gI, gR   device [n_out, rows] upstream gradients of the outputs
@@ -187,7 +189,7 @@ int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_params* p, c
                        const float* keep, size_t keep_bytes,
                        const float* gS, const float* gI, const float* gR, const gnode_params* grads,
                        int64_t rows, int32_t H, void* workspace, size_t workspace_bytes, void* stream,
-                       int32_t sol_info);
+                       int32_t flags, int32_t sol_info);
 
 /* ---- Monte-Carlo SIR labels ------------------------------------------------
  * sir_torch(G, seed_set, beta, gamma, sims, T): ode_nn.py:30-88.
