@@ -25,8 +25,19 @@ struct gnode_graph_s {
     // persistent one-launch integration (gnode_pers64.hip): for 1 / 2 / 4 tiles per workgroup the node each lane-group slot
     // owns, -1 for padding slots; null when the graph never takes that path
     int32_t* persmap[3];
+    // ... and its hub rows (graphs with rows longer than GN_HUB_T): per lane-group slot {first partial slot in the workgroup's
+    // LDS, segments} of the hub row it owns (-1, 0 otherwise); per lane-group slot {first item, items} of the segment sums it
+    // computes each step; the items {first CSR position, one past the last, partial slot, 0}; partial slots per workgroup
+    int32_t* pershub[3];
+    int32_t* perssegptr[3];
+    int32_t* perssegitem[3];
+    int32_t perslds[3];
 };
 
+#define HUB_SEG 32           // a hub row's neighbour list is cut into segments of this many edges
+#ifndef GN_HUB_T
+#define GN_HUB_T 96          // rows longer than this are hubs (measured break-even against the two extra launches per step)
+#endif
 int gn_hub_build(gnode_graph_s* g, const int32_t* rowptr_host);
 int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host);     // the row maps above (gnode_pers64.hip)
 void gn_pers64_free(gnode_graph_s* g);

@@ -30,11 +30,7 @@
 #include <algorithm>
 #include <vector>
 
-#define HUB_SEG 32
-
-#ifndef GN_HUB_T
-#define GN_HUB_T 96          // rows longer than this are hubs (measured break-even against the two extra launches per step)
-#endif
+// HUB_SEG, GN_HUB_T: gnode_common.h (the persistent kernels cut the same segments)
 
 __device__ __forceinline__ float4 hld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void hst4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

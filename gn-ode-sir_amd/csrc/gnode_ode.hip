@@ -586,7 +586,7 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
             return GNODE_ERR_HIP;
         }
     }
-    for (int i = 0; i < 3; ++i) g->persmap[i] = nullptr;
+    for (int i = 0; i < 3; ++i) { g->persmap[i] = g->pershub[i] = g->perssegptr[i] = g->perssegitem[i] = nullptr; g->perslds[i] = 0; }
     int e_build = gn_hub_build(g, rowptr_host);
     if (!e_build) e_build = gn_pers64_build(g, rowptr_host);
     if (int e = e_build) {

@@ -32,7 +32,7 @@
 #include <algorithm>
 #include <vector>
 
-template <bool PRJ, int NT, bool SC1ST>
+template <bool PRJ, int NT, bool SC1ST, bool HUBS>
 __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
     constexpr int STAUX = SC1ST ? 16 : 0;
     // registers: one workgroup per CU, so 256 / 512 / 1024 threads leave 512 / 256 / 128 VGPRs per lane
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
     float* const TB = TA + 16 * TS;                        // Y_S' rows
     float* const T2I = TB + 16 * TS;                       // Z_I'
     float* const T2S = T2I + 16 * TS;                      // Z_S'
+    float* const HP = L + O_T + NT * TEAM_F;               // HUBS: the workgroup's segment partials [slot][64]
     const float* const Wslab = L + O_W + 16 * w * TS;
     const float* const w3s = L + O_W3;
     const int lr = 4 * w + g;
@@ -72,8 +73,11 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
     const int n_steps = a.sched.n_steps;
     // which node this lane group owns: the plan's row map deals degree-sorted quads of rows to the waves (a wave's four
     // rows have similar lengths -- its load count is its longest row's) and the quads round-robin to the workgroups
-    const int node = a.rowmap[idx * (16 * NT) + team * 16 + lr];
+    const int lgslot = idx * (16 * NT) + team * 16 + lr;
+    const int node = a.rowmap[lgslot];
     const bool valid = node >= 0;
+    int hs0 = -1, hcnt = 0, it0 = 0, itn = 0;               // the hub row this lane group owns; the segment sums it computes
+    if (HUBS) { hs0 = a.hubslot[2 * lgslot]; hcnt = a.hubslot[2 * lgslot + 1]; it0 = a.segptr[2 * lgslot]; itn = a.segptr[2 * lgslot + 1]; }
 
 #ifdef GN_PERS_PROF
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memrealtime();
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
         if (valid) {
             const int* h = a.rowhdr + (size_t)node * 20;
             start = h[0]; end = h[1];
+            if (HUBS && hs0 >= 0) end = start;              // a hub row gathers nothing itself: its sum arrives as segment partials
             const int d = end - start;
             if (sub < d) m[0] = (base + (unsigned)h[4 + sub]) * 256u;
 #pragma unroll
@@ -154,8 +159,13 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
             PS_STAMP(0)
             const float4 zs = *reinterpret_cast<const float4*>(T2S + ro);      // Z_S(y_k): the matrix phase behind the last flag
             // ---- gather (step k-1's outputs under its round trip) + SIR update (ode_nn_ngraph_sim.py:75-77) + Euler step
-            const float4 acc = pers_gather<NM, DEPTH>(pers_rsrc(tab_cur, tbytes), a.col, base, m, start, end, sub, lane_b,
-                                                   [&]() { if (k > 0) outputs(k - 1); });
+            float4 acc = pers_gather<NM, DEPTH>(pers_rsrc(tab_cur, tbytes), a.col, base, m, start, end, sub, lane_b,
+                                                [&]() { if (k > 0) outputs(k - 1); });
+            if (HUBS) {
+                pers_hub_partials<DEPTH>(pers_rsrc(tab_cur, tbytes), a.col, a.segitem, it0, itn, base, HP, sub, lane_b);
+                __syncthreads();
+                if (hs0 >= 0) acc = pers_hub_total(HP, hs0, hcnt, sub);
+            }
             PS_STAMP(1)
             float4 dS, dI, dR;
             dS.x = nb * (acc.x * zs.x); dS.y = nb * (acc.y * zs.y); dS.z = nb * (acc.z * zs.z); dS.w = nb * (acc.w * zs.w);
@@ -221,13 +231,19 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
 // length (longest first, ties by id) and cut into quads; quad q goes to wave position q / wgs of workgroup q % wgs: the four
 // rows of a wave have neighbouring lengths, and every workgroup gets quads from the whole length spectrum (equal bytes per CU).
 static const int kPersMaxRows = 256 * 64;              // one resident grid: 256 workgroups x 64 rows
+#define PERS_MAX_PARTIALS 128                          // partial-sum slots (256 B each) a workgroup may need for its hub rows
 int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host) {
-    for (int i = 0; i < 3; ++i) g->persmap[i] = nullptr;
-    if (g->n > kPersMaxRows || g->n_hub > 0) return 0;
+    for (int i = 0; i < 3; ++i) { g->persmap[i] = g->pershub[i] = g->perssegptr[i] = g->perssegitem[i] = nullptr; g->perslds[i] = 0; }
+    if (g->n > kPersMaxRows) return 0;
     std::vector<int32_t> order((size_t)g->n);
     for (int32_t r = 0; r < g->n; ++r) order[r] = r;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-        return rowptr_host[x + 1] - rowptr_host[x] > rowptr_host[y + 1] - rowptr_host[y]; });
+    auto deg = [&](int32_t r) { return rowptr_host[r + 1] - rowptr_host[r]; };
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return deg(x) > deg(y); });
+    auto up = [](int32_t** dst, const std::vector<int32_t>& v) -> hipError_t {
+        hipError_t e = hipMalloc(dst, sizeof(int32_t) * std::max<size_t>(v.size(), 4));
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(*dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice);
+    };
     for (int i = 0; i < 3; ++i) {
         const int nt = 1 << i, per_wg = 16 * nt, wgs = (g->n + per_wg - 1) / per_wg, quads_per_wg = 4 * nt;
         std::vector<int32_t> map((size_t)wgs * per_wg, -1);
@@ -237,22 +253,65 @@ int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host) {
             if (pos >= quads_per_wg) return GNODE_ERR_ARG;
             for (int j = 0; j < 4 && 4 * q + j < g->n; ++j) map[(size_t)wg * per_wg + 4 * pos + j] = order[4 * q + j];
         }
-        GN_HIP(hipMalloc(&g->persmap[i], sizeof(int32_t) * map.size()));
-        GN_HIP(hipMemcpy(g->persmap[i], map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice));
+        // hub rows: the segments of a workgroup's hubs are summed by that workgroup's own lane groups (partials through LDS),
+        // dealt to the lane groups with the least gather work so far; a hub's partial slots are consecutive, in segment order
+        std::vector<int32_t> hub((size_t)wgs * per_wg * 2, 0), segptr((size_t)wgs * per_wg * 2, 0), items;
+        int max_slots = 0;
+        bool ok = true;
+        for (int wg = 0; wg < wgs && ok; ++wg) {
+            std::vector<long> load((size_t)per_wg, 0);
+            std::vector<std::vector<int32_t>> mine((size_t)per_wg);
+            int slots = 0;
+            for (int s = 0; s < per_wg; ++s) {
+                const int32_t r = map[(size_t)wg * per_wg + s];
+                hub[((size_t)wg * per_wg + s) * 2] = -1;
+                if (r >= 0 && deg(r) <= GN_HUB_T) load[s] = deg(r);
+            }
+            for (int s = 0; s < per_wg; ++s) {
+                const int32_t r = map[(size_t)wg * per_wg + s];
+                if (r < 0 || deg(r) <= GN_HUB_T) continue;
+                const int32_t lo = rowptr_host[r], hi = rowptr_host[r + 1];
+                hub[((size_t)wg * per_wg + s) * 2] = slots;
+                hub[((size_t)wg * per_wg + s) * 2 + 1] = (hi - lo + HUB_SEG - 1) / HUB_SEG;
+                for (int32_t e = lo; e < hi; e += HUB_SEG) {
+                    int best = 0;
+                    for (int t = 1; t < per_wg; ++t) if (load[t] < load[best]) best = t;
+                    load[best] += HUB_SEG;
+                    mine[best].push_back(e); mine[best].push_back(std::min(hi, e + HUB_SEG)); mine[best].push_back(slots++); mine[best].push_back(0);
+                }
+            }
+            if (slots > PERS_MAX_PARTIALS) ok = false;
+            max_slots = std::max(max_slots, slots);
+            for (int s = 0; s < per_wg; ++s) {
+                segptr[((size_t)wg * per_wg + s) * 2] = (int32_t)(items.size() / 4);
+                segptr[((size_t)wg * per_wg + s) * 2 + 1] = (int32_t)(mine[s].size() / 4);
+                items.insert(items.end(), mine[s].begin(), mine[s].end());
+            }
+        }
+        if (!ok) continue;                                  // this tile count is not available for this graph (plan skips it)
+        GN_HIP(up(&g->persmap[i], map));
+        GN_HIP(up(&g->pershub[i], hub));
+        GN_HIP(up(&g->perssegptr[i], segptr));
+        GN_HIP(up(&g->perssegitem[i], items));
+        g->perslds[i] = max_slots;
     }
     return 0;
 }
 void gn_pers64_free(gnode_graph_s* g) {
-    for (int i = 0; i < 3; ++i) if (g->persmap[i]) { (void)hipFree(g->persmap[i]); g->persmap[i] = nullptr; }
+    for (int i = 0; i < 3; ++i) {
+        for (int32_t** q : {&g->persmap[i], &g->pershub[i], &g->perssegptr[i], &g->perssegitem[i]})
+            if (*q) { (void)hipFree(*q); *q = nullptr; }
+    }
 }
 
 bool gn_pers64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p) {
-    if (n_steps < 1 || n_steps > 128 || B < 1 || g->n_hub > 0 || !g->persmap[0]) return false;
+    if (n_steps < 1 || n_steps > 128 || B < 1) return false;
     const int n_xcc = 8;
     if (g->num_cu < 64 || g->num_cu % n_xcc) return false;
     const int slots = g->num_cu / n_xcc;
     if ((long)B * g->n >= (1L << 24)) return false;
     for (int nt = 1; nt <= 4; nt *= 2) {
+        if (!g->persmap[nt == 1 ? 0 : nt == 2 ? 1 : 2]) continue;      // graph too large, or its hub rows need too many partial slots
         const int wgs = (g->n + 16 * nt - 1) / (16 * nt);
         PersPlan q;
         q.nt = nt; q.wgs = wgs; q.n_xcc = n_xcc; q.slots = slots;
@@ -275,13 +334,14 @@ bool gn_pers64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p) {
 
 size_t gn_pers64_ctl_bytes() { return gn_align(sizeof(PersCtl)); }
 
-static size_t pers_lds_bytes(int nt) {
-    const size_t need = sizeof(float) * ((size_t)64 * TS + 256 + (size_t)nt * 4 * 16 * TS);
+static size_t pers_lds_bytes(int nt, int partial_slots = PERS_MAX_PARTIALS) {
+    const size_t need = sizeof(float) * ((size_t)64 * TS + 256 + (size_t)nt * 4 * 16 * TS + (size_t)partial_slots * 64);
     return std::max<size_t>(need, 84 * 1024);              // > half of the CU's 160 KB: ONE workgroup per CU
 }
 
 int gn_pers64_set_attributes() {
-#define PS_ATTR(P, N, S) GN_HIP(hipFuncSetAttribute((const void*)k_pers64<P, N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pers_lds_bytes(N)));
+#define PS_ATTR(P, N, S) GN_HIP(hipFuncSetAttribute((const void*)k_pers64<P, N, S, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pers_lds_bytes(N))); \
+                         GN_HIP(hipFuncSetAttribute((const void*)k_pers64<P, N, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pers_lds_bytes(N)));
     PS_ATTR(true, 1, false) PS_ATTR(true, 1, true) PS_ATTR(true, 2, false) PS_ATTR(true, 2, true) PS_ATTR(true, 4, false) PS_ATTR(true, 4, true)
     PS_ATTR(false, 1, false) PS_ATTR(false, 1, true) PS_ATTR(false, 2, false) PS_ATTR(false, 2, true) PS_ATTR(false, 4, false) PS_ATTR(false, 4, true)
 #undef PS_ATTR
@@ -293,7 +353,10 @@ int gn_launch_pers64(const gnode_graph_s* g, const PersPlan& pl, long rows, cons
                      const int* slot_host, int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol, float* keep,
                      void* ctl, hipStream_t st) {
     PersArgs a;
-    a.rowhdr = g->rowhdr; a.col = g->col; a.rowmap = g->persmap[pl.nt == 1 ? 0 : pl.nt == 2 ? 1 : 2]; a.n = g->n; a.B = (int)(rows / g->n); a.rows = (unsigned)rows;
+    const int vi = pl.nt == 1 ? 0 : pl.nt == 2 ? 1 : 2;
+    const bool hubs = g->n_hub > 0;
+    a.rowhdr = g->rowhdr; a.col = g->col; a.rowmap = g->persmap[vi]; a.n = g->n;
+    a.hubslot = hubs ? g->pershub[vi] : nullptr; a.segptr = hubs ? g->perssegptr[vi] : nullptr; a.segitem = hubs ? g->perssegitem[vi] : nullptr; a.B = (int)(rows / g->n); a.rows = (unsigned)rows;
     a.pp = pers_place_of(pl);
     a.Y0 = Y0; a.PR0 = PR0; a.beta = beta; a.gamma = gamma; a.Z0 = Z0; a.Z1 = Z1; a.keep = keep;
     a.W = W; a.bias = bias; a.w3 = p->linear3_weight; a.b3 = p->linear3_bias; a.w2 = p->linearS2_weight; a.b2 = p->linearS2_bias;
@@ -303,8 +366,9 @@ int gn_launch_pers64(const gnode_graph_s* g, const PersPlan& pl, long rows, cons
     GN_HIP(hipMemsetAsync(ctl, 0, sizeof(PersCtl), st));  // tickets, flags, give-up word: zeroed before EVERY launch (a memset node under capture)
     const bool prj = PR0 != nullptr, sc1 = pl.span > 1;
     const dim3 grid((unsigned)(pl.n_xcc * pl.slots));
-#define PS_GO(P, N, S) hipLaunchKernelGGL((k_pers64<P, N, S>), grid, dim3(256 * N), pers_lds_bytes(N), st, a)
-#define PS_NT(P, S) { if (pl.nt == 1) PS_GO(P, 1, S); else if (pl.nt == 2) PS_GO(P, 2, S); else PS_GO(P, 4, S); }
+#define PS_GO(P, N, S) { if (hubs) hipLaunchKernelGGL((k_pers64<P, N, S, true>), grid, dim3(256 * N), pers_lds_bytes(N, g->perslds[vi]), st, a); \
+                         else hipLaunchKernelGGL((k_pers64<P, N, S, false>), grid, dim3(256 * N), pers_lds_bytes(N, 0), st, a); }
+#define PS_NT(P, S) { if (pl.nt == 1) PS_GO(P, 1, S) else if (pl.nt == 2) PS_GO(P, 2, S) else PS_GO(P, 4, S) }
     if (prj) { if (sc1) PS_NT(true, true) else PS_NT(true, false) }
     else { if (sc1) PS_NT(false, true) else PS_NT(false, false) }
 #undef PS_NT

@@ -25,6 +25,7 @@
 
 struct PersBwdArgs {
     const int* rowhdr; const int* col; const int* rowmap;
+    const int* hubslot; const int* segptr; const int* segitem;
     int n, B, b0; unsigned rows;
     PersPlace pp;
     int G;                               // grid points; intervals i = G-2 .. 1 are run here
@@ -40,7 +41,7 @@ struct PersBwdArgs {
     short slot[128];                     // slot[i]: output row of grid point i-1, or -1
 };
 
-template <int NT, bool SC1ST>
+template <int NT, bool SC1ST, bool HUBS>
 __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
     constexpr int STAUX = SC1ST ? 16 : 0;
     constexpr int NM = 4;                                  // neighbour-id registers (16 ids each)
@@ -69,13 +70,17 @@ __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
     float* const Gt0 = Yt1 + 16 * TS;
     float* const Gt1 = Gt0 + 16 * TS;
     const float* const Wl = L + O_W;
+    float* const HP = L + O_T + NT * TEAM_F;               // HUBS: the workgroup's segment partials [slot][64]
     const int lr = 4 * w + g, ro = lr * TS + 4 * sub;
     const unsigned lane_b = 16u * sub;
     const unsigned rows = a.rows;
     const unsigned tbytes = (rows + 1u) * 256u;
     const size_t slab = (size_t)rows * 64;
-    const int node = a.rowmap[idx * (16 * NT) + team * 16 + lr];
+    const int lgslot = idx * (16 * NT) + team * 16 + lr;
+    const int node = a.rowmap[lgslot];
     const bool valid = node >= 0;
+    int hs0 = -1, hcnt = 0, it0 = 0, itn = 0;               // the hub row this lane group owns; the segment sums it computes
+    if (HUBS) { hs0 = a.hubslot[2 * lgslot]; hcnt = a.hubslot[2 * lgslot + 1]; it0 = a.segptr[2 * lgslot]; itn = a.segptr[2 * lgslot + 1]; }
     const unsigned base = (unsigned)b * (unsigned)a.n;
     const unsigned row = valid ? base + (unsigned)node : 0u;
     const unsigned off = row * 256u + lane_b;
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
     if (valid) {
         const int* h = a.rowhdr + (size_t)node * 20;
         start = h[0]; end = h[1];
+        if (HUBS && hs0 >= 0) end = start;                  // a hub row's sum arrives as segment partials
         const int d = end - start;
         if (sub < d) m[0] = (base + (unsigned)h[4 + sub]) * 256u;
 #pragma unroll
@@ -140,7 +146,12 @@ __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
             if (sh[2] == 0u) return;
         }
         // ---- A q: the transposed gather (A symmetric: same neighbour lists), ascending column order
-        const float4 gq = pers_gather<NM, DEPTH>(pers_rsrc(a.Q[cur], tbytes), a.col, base, m, start, end, sub, lane_b, []() {});
+        float4 gq = pers_gather<NM, DEPTH>(pers_rsrc(a.Q[cur], tbytes), a.col, base, m, start, end, sub, lane_b, []() {});
+        if (HUBS) {
+            pers_hub_partials<DEPTH>(pers_rsrc(a.Q[cur], tbytes), a.col, a.segitem, it0, itn, base, HP, sub, lane_b);
+            __syncthreads();
+            if (hs0 >= 0) gq = pers_hub_total(HP, hs0, hcnt, sub);
+        }
         const Pre p = pre;
         {
             float4 dS, dI;
@@ -241,13 +252,14 @@ __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
 }
 
 // --------------------------------------------------------------------------- host
-static size_t pers_bwd_lds_bytes(int nt) {
-    const size_t need = sizeof(float) * ((size_t)64 * TS + (size_t)nt * 6 * 16 * TS);
+static size_t pers_bwd_lds_bytes(int nt, int partial_slots = 128) {
+    const size_t need = sizeof(float) * ((size_t)64 * TS + (size_t)nt * 6 * 16 * TS + (size_t)partial_slots * 64);
     return std::max<size_t>(need, 84 * 1024);              // > half of the CU's 160 KB: ONE workgroup per CU
 }
 
 int gn_pers_bwd64_set_attributes() {
-#define PB_ATTR(N, S) GN_HIP(hipFuncSetAttribute((const void*)k_pers_bwd64<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pers_bwd_lds_bytes(N)));
+#define PB_ATTR(N, S) GN_HIP(hipFuncSetAttribute((const void*)k_pers_bwd64<N, S, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pers_bwd_lds_bytes(N))); \
+                      GN_HIP(hipFuncSetAttribute((const void*)k_pers_bwd64<N, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pers_bwd_lds_bytes(N)));
     PB_ATTR(1, false) PB_ATTR(1, true) PB_ATTR(2, false) PB_ATTR(2, true)
 #undef PB_ATTR
     return 0;
@@ -262,7 +274,10 @@ int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, 
                          const int* slot_of_prev /* [G]: output row of grid point i-1 for interval i, or -1 */, void* ctl,
                          int* slots, hipStream_t st) {
     PersBwdArgs x;
-    x.rowhdr = g->rowhdr; x.col = g->col; x.rowmap = g->persmap[pl.nt == 1 ? 0 : pl.nt == 2 ? 1 : 2];
+    const int vi = pl.nt == 1 ? 0 : 1;
+    const bool hubs = g->n_hub > 0;
+    x.rowhdr = g->rowhdr; x.col = g->col; x.rowmap = g->persmap[vi];
+    x.hubslot = hubs ? g->pershub[vi] : nullptr; x.segptr = hubs ? g->perssegptr[vi] : nullptr; x.segitem = hubs ? g->perssegitem[vi] : nullptr;
     x.n = g->n; x.B = (int)(rows / g->n); x.rows = (unsigned)rows; x.pp = pers_place_of(pl); x.G = G;
     x.Q[0] = Q0; x.Q[1] = Q1; x.sol = sol; x.keep = keep; x.W = W; x.beta = beta; x.gamma = gamma; x.a = a; x.part = part;
     x.gS = gS; x.gI = gI; x.gR = gR;
@@ -276,9 +291,10 @@ int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, 
     for (int b0 = 0; b0 < x.B; b0 += pl.concurrent) {
         x.b0 = b0;
         GN_HIP(hipMemsetAsync(ctl, 0, sizeof(PersCtl), st));
-#define PB_GO(N, S) hipLaunchKernelGGL((k_pers_bwd64<N, S>), grid, dim3(256 * N), pers_bwd_lds_bytes(N), st, x)
-        if (pl.nt == 1) { if (sc1) PB_GO(1, true); else PB_GO(1, false); }
-        else { if (sc1) PB_GO(2, true); else PB_GO(2, false); }
+#define PB_GO(N, S) { if (hubs) hipLaunchKernelGGL((k_pers_bwd64<N, S, true>), grid, dim3(256 * N), pers_bwd_lds_bytes(N, g->perslds[vi]), st, x); \
+                      else hipLaunchKernelGGL((k_pers_bwd64<N, S, false>), grid, dim3(256 * N), pers_bwd_lds_bytes(N, 0), st, x); }
+        if (pl.nt == 1) { if (sc1) PB_GO(1, true) else PB_GO(1, false) }
+        else { if (sc1) PB_GO(2, true) else PB_GO(2, false) }
 #undef PB_GO
         GN_LAUNCH_CHECK();
     }
@@ -287,12 +303,13 @@ int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, 
 }
 
 // The sweep's plan: 1 or 2 tiles per workgroup only (its per-row state -- adjoint, gradient accumulators, the interval's own
-// rows -- does not fit the 128 registers a 1024-thread workgroup leaves), up to 4 consecutive launches
+// rows -- does not fit the 128 registers a 1024-thread workgroup leaves), up to 2 consecutive launches (measured: 4 launches at
+// 600 nodes x 32 samples lose to one launch per interval)
 bool gn_pers_bwd64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p) {
-    if (n_steps < 2 || n_steps > 127 || B < 1 || g->n_hub > 0 || !g->persmap[0]) return false;
+    if (n_steps < 2 || n_steps > 127 || B < 1) return false;
     for (long conc = B; conc >= 1; conc = (conc + 1) / 2) {
         PersPlan q;
-        if (gn_pers64_plan(g, conc, n_steps, &q) && q.nt <= 2 && (B + q.concurrent - 1) / q.concurrent <= 4 && q.wgs <= BWD_NWG) { *p = q; return true; }
+        if (gn_pers64_plan(g, conc, n_steps, &q) && q.nt <= 2 && (B + q.concurrent - 1) / q.concurrent <= 2 && q.wgs <= BWD_NWG) { *p = q; return true; }
         if (conc == 1) break;
     }
     return false;

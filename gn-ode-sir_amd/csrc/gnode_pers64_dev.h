@@ -144,6 +144,34 @@ __device__ __forceinline__ bool pers_wait(unsigned* flags, int wgs, unsigned epo
 }
 
 
+// Hub rows (longer than GN_HUB_T; gnode_hub.hip has the story): the row map deals a graph's hubs evenly to the workgroups, and
+// a hub's <= 32-edge segments are summed by lane groups of ITS OWN workgroup (the plan's work lists), partials through LDS --
+// the same segments, the same ascending sums and the same segment-order total as k_hub_seg + the consumers of the per-step
+// kernels, so the bits agree, and no second group barrier is needed.  This lane group's items: [it0, it0 + itn).
+template <int DEPTH>
+__device__ __forceinline__ void pers_hub_partials(rsrc_t tab, const int* __restrict__ col, const int* __restrict__ items, int it0, int itn,
+                                                  unsigned base, float* __restrict__ P, int sub, unsigned lane_b) {
+    for (int t = 0; __any(t < itn); ++t) {
+        int lo = 0, hi = 0, slot = 0;
+        if (t < itn) { const int* it = items + 4 * (size_t)(it0 + t); lo = it[0]; hi = it[1]; slot = it[2]; }
+        const int cnt = hi - lo;
+        unsigned ms[2];
+        ms[0] = (sub < cnt) ? (base + (unsigned)col[lo + sub]) * 256u : PS_OOB;
+        ms[1] = (16 + sub < cnt) ? (base + (unsigned)col[lo + 16 + sub]) * 256u : PS_OOB;
+        const float4 part = pers_gather<2, DEPTH>(tab, col, base, ms, 0, cnt, sub, lane_b, []() {});
+        if (t < itn) *reinterpret_cast<float4*>(P + (size_t)slot * 64 + 4 * sub) = part;
+    }
+}
+// the hub row's sum: its partials in segment order (what the per-step consumers do: hs = 0; hs += partial_s)
+__device__ __forceinline__ float4 pers_hub_total(const float* __restrict__ P, int hs0, int hcnt, int sub) {
+    float4 hs = zero4();
+    for (int s = 0; s < hcnt; ++s) {
+        const float4 u = *reinterpret_cast<const float4*>(P + (size_t)(hs0 + s) * 64 + 4 * sub);
+        hs.x += u.x; hs.y += u.y; hs.z += u.z; hs.w += u.w;
+    }
+    return hs;
+}
+
 // Which sample ("group" gl) and which of its workgroups (idx) this workgroup is: read the XCD from the hardware register,
 // draw a ticket there (PersPlan in gnode_pers64.h).  `sh`: 4 words of LDS; ends with a workgroup barrier.  false: idle.
 __device__ __forceinline__ bool pers_place(const PersPlace& pp, PersCtl* ctl, unsigned* sh, int& gl, int& idx) {

@@ -24,6 +24,28 @@ def er_csr(n: int, m: int, seed: int = 0):
     return A.indptr.astype(np.int32), A.indices.astype(np.int32)
 
 
+def heavy_tail_csr(n: int, m: int, exponent: float = 0.5, seed: int = 0):
+    """A graph with the degree tail of the reference's real datasets (fb-social's longest row ~700 of 1 893 nodes,
+    wiki-vote's ~1 065 of 7 066: SURVEY section 7): m distinct undirected edges whose endpoints are drawn with probability
+    ~ (rank + 1)^-exponent (Chung-Lu), no self-loops; the big nodes come first, as in many real node numberings.
+    Symmetrised CSR int32 with sorted columns -> (rowptr, col)."""
+    rng = np.random.default_rng(seed)
+    w = (np.arange(n) + 1.0) ** (-exponent)
+    p = w / w.sum()
+    keys = np.empty(0, dtype=np.int64)
+    while keys.shape[0] < m:
+        k = int((m - keys.shape[0]) * 1.5) + 64
+        u, v = rng.choice(n, size=k, p=p), rng.choice(n, size=k, p=p)
+        keep = u != v
+        keys = np.unique(np.concatenate([keys, np.minimum(u, v)[keep].astype(np.int64) * n + np.maximum(u, v)[keep]]))
+        if keys.shape[0] > m:
+            keys = np.sort(rng.permutation(keys)[:m])
+    a, b = keys // n, keys % n
+    A = sp.coo_matrix((np.ones(2 * m, dtype=np.int8), (np.concatenate([a, b]), np.concatenate([b, a]))), shape=(n, n)).tocsr()
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32)
+
+
 def linear_params(H: int, seed: int = 0):
     """The eight trained tensors with `nn.Linear`'s default init U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (the reference
     never calls its init_weights, ode_nn_ngraph_sim.py:52,137), from a numpy generator."""

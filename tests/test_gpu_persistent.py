@@ -16,11 +16,12 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _setup(n, m, B, seed, dev):
+def _setup(n, m, B, seed, dev, tail=0.0):
     import torch
     from gnode import ops, synth
     from gnode.graph import DeviceGraph
-    rp, ci = synth.er_csr(n, m, seed=seed)
+    # tail > 0: Chung-Lu degrees with the reference datasets' tails (hub rows: longest ~740 at fb-social size, ~1 020 at wiki-vote size)
+    rp, ci = synth.heavy_tail_csr(n, m, tail, seed=seed) if tail else synth.er_csr(n, m, seed=seed)
     g = DeviceGraph(rp, ci)
     P = {k: torch.from_numpy(v).to(dev) for k, v in synth.linear_params(64, seed=seed + 1).items()}
     x = torch.from_numpy(synth.samples(n, B, 64, seed=seed + 2)).to(dev).reshape(B * n, 67)
@@ -32,11 +33,14 @@ SHAPES = [(1893, 13835, 1, 4), (1893, 13835, 8, 1), (1893, 13835, 3, 2), (600, 2
           (7066, 100736, 1, 8), (7066, 100736, 2, 4), (130, 500, 2, 1), (4099, 30000, 2, 4)]
 
 
-@pytest.mark.parametrize("n,m,B,span", SHAPES)
-def test_persistent_inference_bitwise(n, m, B, span, dev):
+HUB_SHAPES = [(1893, 13835, 1, 4, 0.8), (1893, 13835, 8, 1, 0.8), (7066, 100736, 1, 8, 0.5), (7066, 100736, 2, 4, 0.5), (500, 6000, 3, 1, 0.9)]
+
+
+@pytest.mark.parametrize("n,m,B,span,tail", [s + (0.0,) for s in SHAPES] + HUB_SHAPES)
+def test_persistent_inference_bitwise(n, m, B, span, tail, dev):
     import torch
     from gnode import ops
-    g, P, x = _setup(n, m, B, 7, dev)
+    g, P, x = _setup(n, m, B, 7, dev, tail)
     maxTime, deltaT = 30, 0.5
     dts = ops.step_sizes(ops.time_grid(maxTime, deltaT))
     path, plan = ops.forward_path(g, B * n, 64, len(dts))
@@ -56,11 +60,12 @@ def test_persistent_inference_bitwise(n, m, B, span, dev):
 
 
 @pytest.mark.parametrize("keep", [True, False], ids=["kept", "nokeep"])
-@pytest.mark.parametrize("n,m,B,span", [(1893, 13835, 1, 4), (1893, 13835, 8, 1), (600, 2400, 5, 1), (7066, 100736, 1, 8)])
-def test_persistent_training_forward_bitwise(n, m, B, span, keep, dev):
+@pytest.mark.parametrize("n,m,B,span,tail", [(1893, 13835, 1, 4, 0.0), (1893, 13835, 8, 1, 0.0), (600, 2400, 5, 1, 0.0), (7066, 100736, 1, 8, 0.0),
+                                             (1893, 13835, 2, 4, 0.8), (7066, 100736, 1, 8, 0.5)])
+def test_persistent_training_forward_bitwise(n, m, B, span, tail, keep, dev):
     import torch
     from gnode import ops
-    g, P, x = _setup(n, m, B, 11, dev)
+    g, P, x = _setup(n, m, B, 11, dev, tail)
     maxTime, deltaT = 12, 0.5
     dts = ops.step_sizes(ops.time_grid(maxTime, deltaT))
     rows_out = ops.subsample_rows(maxTime, deltaT)
@@ -88,16 +93,17 @@ def test_persistent_training_forward_bitwise(n, m, B, span, keep, dev):
         assert torch.equal(sol0[1:G - 1, 3 * rows:], sol1[1:G - 1, 3 * rows:])         # A Z_I(y_k) parked in the 4th slabs
 
 
-@pytest.mark.parametrize("n,m,B,launches", [(1893, 13835, 1, 1), (1893, 13835, 2, 1), (1893, 13835, 8, 2), (600, 2400, 5, 1),
-                                            (7066, 100736, 1, 1), (130, 500, 3, 1)])
-def test_persistent_backward(n, m, B, launches, dev):
+@pytest.mark.parametrize("n,m,B,launches,tail", [(1893, 13835, 1, 1, 0.0), (1893, 13835, 2, 1, 0.0), (1893, 13835, 8, 2, 0.0), (600, 2400, 5, 1, 0.0),
+                                                 (7066, 100736, 1, 1, 0.0), (130, 500, 3, 1, 0.0), (1893, 13835, 1, 1, 0.8), (1893, 13835, 8, 2, 0.8),
+                                                 (7066, 100736, 1, 1, 0.5)])
+def test_persistent_backward(n, m, B, launches, tail, dev):
     """The adjoint sweep as ONE persistent launch (csrc/gnode_pers64_bwd.hip; `launches` consecutive ones when the batch does
     not fit one resident grid) against one launch per interval: the same per-row VJPs, rows enter the parameter sums in a
     different order -> 1e-5 of each gradient's scale; bitwise reproducible run to run.  Forwards persistent and per-step
     (bit-identical trajectories, checked above) are crossed with both backwards."""
     import torch
     from gnode import ops
-    g, P, x = _setup(n, m, B, 5, dev)
+    g, P, x = _setup(n, m, B, 5, dev, tail)
     maxTime, deltaT = 30, 0.5
     dts = ops.step_sizes(ops.time_grid(maxTime, deltaT))
     rows_out = ops.subsample_rows(maxTime, deltaT)

@@ -54,6 +54,11 @@ def main():
                 out[key + "_fwd_ms"] = round(t, 4)
                 out[key + "_us_per_step"] = round(1e3 * t / len(dts), 2)
                 out[key + "_train_fwd_ms"] = round(tt, 4)
+                gs = [torch.randn(len(rows_out), B * n, device=dev) for _ in range(3)]
+                S_, I_, R_, sol = ops.forward(g, x, P, dts, "euler", rows_out, want_sol=True, workspace=ws, persist=persist)
+                tb = ev_time(lambda: ops.backward(g, x, P, dts, "euler", rows_out, sol, *gs, persist=persist), 10)
+                out[key + "_bwd_ms"] = round(tb, 4)
+                del sol
                 assert ops.forward_status() == 0
                 if persist and path == 2 and "--prof" in sys.argv:          # library built with GNODE_EXTRA_FLAGS=-DGN_PERS_PROF
                     import ctypes as C
