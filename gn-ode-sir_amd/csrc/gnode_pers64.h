@@ -30,7 +30,7 @@ struct PersSched { float dt[128]; short slot[128]; int n_steps; };
 struct PersArgs {
     const int* rowhdr; const int* col; const int* rowmap;   // rowmap: lane-group slot -> node (or -1), per tile count (gnode_graph_s::persmap)
     const int* hubslot; const int* segptr; const int* segitem;   // hub work lists (gnode_graph_s::pershub ...), null without hub rows
-    int n, B; unsigned rows;
+    int n, B, lds_slots; unsigned rows;
     PersPlace pp;
     const float* Y0; const float* PR0; const float* beta; const float* gamma;
     float* Z0; float* Z1; float* keep;

@@ -36,7 +36,7 @@ template <bool PRJ, int NT, bool SC1ST, bool HUBS>
 __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
     constexpr int STAUX = SC1ST ? 16 : 0;
     // registers: one workgroup per CU, so 256 / 512 / 1024 threads leave 512 / 256 / 128 VGPRs per lane
-    constexpr int NM = NT == 4 ? 2 : 4;                    // neighbour-id registers (16 ids each)
+    constexpr int NM = 6;                                  // neighbour-id registers (16 ids each): every row up to the hub threshold (96)
 #ifndef GN_PERS_DEPTH
 #define GN_PERS_DEPTH 4
 #endif
@@ -58,10 +58,12 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
     float* const TB = TA + 16 * TS;                        // Y_S' rows
     float* const T2I = TB + 16 * TS;                       // Z_I'
     float* const T2S = T2I + 16 * TS;                      // Z_S'
-    float* const HP = L + O_T + NT * TEAM_F;               // HUBS: the workgroup's segment partials [slot][64]
+    float* const HP = L + O_T + NT * TEAM_F;               // HUBS: segment partials [S][64] | segment ids [S][32] | item lists (gnode_pers64_dev.h)
     const float* const Wslab = L + O_W + 16 * w * TS;
     const float* const w3s = L + O_W3;
     const int lr = 4 * w + g;
+    unsigned* const HI = reinterpret_cast<unsigned*>(HP + (size_t)a.lds_slots * 64);
+    unsigned* const HLmine = HI + (size_t)a.lds_slots * 32 + (size_t)(team * 16 + lr) * PERS_MAX_ITEMS;
     const unsigned lane_b = 16u * sub;
     const int ro = lr * TS + 4 * sub;
     const int fo = (lane & 15) * TS + 16 * (lane >> 4);
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
             for (int j = 1; j < NM; ++j)
                 if (16 * j + sub < d) m[j] = (base + (unsigned)a.col[start + 16 * j + sub]) * 256u;
         }
+        if (HUBS) pers_hub_stage(a.col, a.segitem, it0, itn, base, HI, HLmine, sub);    // (the barriers below publish it)
         float4 ys = zero4(), yi = zero4(), yr = zero4(), pr = zero4(), zi = zero4();
         float nb = 0.f, gm = 0.f;
         if (valid) {
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
             float4 acc = pers_gather<NM, DEPTH>(pers_rsrc(tab_cur, tbytes), a.col, base, m, start, end, sub, lane_b,
                                                 [&]() { if (k > 0) outputs(k - 1); });
             if (HUBS) {
-                pers_hub_partials<DEPTH>(pers_rsrc(tab_cur, tbytes), a.col, a.segitem, it0, itn, base, HP, sub, lane_b);
+                pers_hub_partials<(NT == 4 ? 1 : 4)>(pers_rsrc(tab_cur, tbytes), a.col, itn, HI, HLmine, HP, sub, lane_b);
                 __syncthreads();
                 if (hs0 >= 0) acc = pers_hub_total(HP, hs0, hcnt, sub);
             }
@@ -228,8 +231,8 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
 
 // --------------------------------------------------------------------------- host: row maps, plan, launch
 // Slot s of the map for nt tiles per workgroup = lane group (s % (16 nt)) of workgroup s / (16 nt).  Rows are sorted by
-// length (longest first, ties by id) and cut into quads; quad q goes to wave position q / wgs of workgroup q % wgs: the four
-// rows of a wave have neighbouring lengths, and every workgroup gets quads from the whole length spectrum (equal bytes per CU).
+// length (longest first, ties by id); hub rows are dealt singly, the others in quads, round-robin: the four rows of a wave have
+// neighbouring lengths, and every workgroup gets rows from the whole length spectrum (equal bytes per CU).
 static const int kPersMaxRows = 256 * 64;              // one resident grid: 256 workgroups x 64 rows
 #define PERS_MAX_PARTIALS 128                          // partial-sum slots (256 B each) a workgroup may need for its hub rows
 int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host) {
@@ -247,12 +250,24 @@ int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host) {
     for (int i = 0; i < 3; ++i) {
         const int nt = 1 << i, per_wg = 16 * nt, wgs = (g->n + per_wg - 1) / per_wg, quads_per_wg = 4 * nt;
         std::vector<int32_t> map((size_t)wgs * per_wg, -1);
-        const int nq = (g->n + 3) / 4;
-        for (int q = 0; q < nq; ++q) {
-            const int wg = q % wgs, pos = q / wgs;          // pos < quads_per_wg because nq <= wgs * quads_per_wg
-            if (pos >= quads_per_wg) return GNODE_ERR_ARG;
-            for (int j = 0; j < 4 && 4 * q + j < g->n; ++j) map[(size_t)wg * per_wg + 4 * pos + j] = order[4 * q + j];
+        // hub rows first, ONE AT A TIME round-robin (their segment sums are work for the owner's workgroup: the biggest hubs
+        // must not share one), then the other rows in quads of neighbouring lengths, round-robin over the workgroups with room
+        std::vector<int> fill((size_t)wgs, 0);
+        int32_t nh = 0;
+        while (nh < g->n && deg(order[nh]) > GN_HUB_T) ++nh;
+        if ((long)nh > (long)wgs * per_wg / 2) { continue; }   // (half the slots hubs: not a graph for this path)
+        for (int32_t h = 0; h < nh; ++h) { const int wg = h % wgs; map[(size_t)wg * per_wg + fill[wg]++] = order[h]; }
+        {
+            int wg = 0;
+            for (int32_t r = nh; r < g->n;) {
+                int guard = 0;
+                while (fill[wg] >= per_wg && guard++ < wgs) wg = (wg + 1) % wgs;
+                if (fill[wg] >= per_wg) return GNODE_ERR_ARG;   // cannot happen: wgs * per_wg >= n
+                for (int j = 0; j < 4 && r < g->n && fill[wg] < per_wg; ++j) map[(size_t)wg * per_wg + fill[wg]++] = order[r++];
+                wg = (wg + 1) % wgs;
+            }
         }
+        (void)quads_per_wg;
         // hub rows: the segments of a workgroup's hubs are summed by that workgroup's own lane groups (partials through LDS),
         // dealt to the lane groups with the least gather work so far; a hub's partial slots are consecutive, in segment order
         std::vector<int32_t> hub((size_t)wgs * per_wg * 2, 0), segptr((size_t)wgs * per_wg * 2, 0), items;
@@ -281,6 +296,7 @@ int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host) {
                 }
             }
             if (slots > PERS_MAX_PARTIALS) ok = false;
+            for (int s = 0; s < per_wg; ++s) if (mine[s].size() / 4 > PERS_MAX_ITEMS) ok = false;
             max_slots = std::max(max_slots, slots);
             for (int s = 0; s < per_wg; ++s) {
                 segptr[((size_t)wg * per_wg + s) * 2] = (int32_t)(items.size() / 4);
@@ -335,7 +351,7 @@ bool gn_pers64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p) {
 size_t gn_pers64_ctl_bytes() { return gn_align(sizeof(PersCtl)); }
 
 static size_t pers_lds_bytes(int nt, int partial_slots = PERS_MAX_PARTIALS) {
-    const size_t need = sizeof(float) * ((size_t)64 * TS + 256 + (size_t)nt * 4 * 16 * TS + (size_t)partial_slots * 64);
+    const size_t need = sizeof(float) * ((size_t)64 * TS + 256 + (size_t)nt * 4 * 16 * TS + (size_t)partial_slots * 96 + (size_t)16 * nt * PERS_MAX_ITEMS);
     return std::max<size_t>(need, 84 * 1024);              // > half of the CU's 160 KB: ONE workgroup per CU
 }
 
@@ -356,6 +372,7 @@ int gn_launch_pers64(const gnode_graph_s* g, const PersPlan& pl, long rows, cons
     const int vi = pl.nt == 1 ? 0 : pl.nt == 2 ? 1 : 2;
     const bool hubs = g->n_hub > 0;
     a.rowhdr = g->rowhdr; a.col = g->col; a.rowmap = g->persmap[vi]; a.n = g->n;
+    a.lds_slots = hubs ? g->perslds[vi] : 0;
     a.hubslot = hubs ? g->pershub[vi] : nullptr; a.segptr = hubs ? g->perssegptr[vi] : nullptr; a.segitem = hubs ? g->perssegitem[vi] : nullptr; a.B = (int)(rows / g->n); a.rows = (unsigned)rows;
     a.pp = pers_place_of(pl);
     a.Y0 = Y0; a.PR0 = PR0; a.beta = beta; a.gamma = gamma; a.Z0 = Z0; a.Z1 = Z1; a.keep = keep;

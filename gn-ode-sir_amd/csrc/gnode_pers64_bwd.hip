@@ -26,7 +26,7 @@
 struct PersBwdArgs {
     const int* rowhdr; const int* col; const int* rowmap;
     const int* hubslot; const int* segptr; const int* segitem;
-    int n, B, b0; unsigned rows;
+    int n, B, b0, lds_slots; unsigned rows;
     PersPlace pp;
     int G;                               // grid points; intervals i = G-2 .. 1 are run here
     float* Q[2];                         // q tables [rows + 1][64]; interval i gathers Q[(G-1-i) & 1]
@@ -44,7 +44,7 @@ struct PersBwdArgs {
 template <int NT, bool SC1ST, bool HUBS>
 __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
     constexpr int STAUX = SC1ST ? 16 : 0;
-    constexpr int NM = 4;                                  // neighbour-id registers (16 ids each)
+    constexpr int NM = 6;                                  // neighbour-id registers (16 ids each): every row up to the hub threshold (96)
 #ifndef GN_PERS_BWD_DEPTH
 #define GN_PERS_BWD_DEPTH 2
 #endif
@@ -70,8 +70,10 @@ __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
     float* const Gt0 = Yt1 + 16 * TS;
     float* const Gt1 = Gt0 + 16 * TS;
     const float* const Wl = L + O_W;
-    float* const HP = L + O_T + NT * TEAM_F;               // HUBS: the workgroup's segment partials [slot][64]
+    float* const HP = L + O_T + NT * TEAM_F;               // HUBS: segment partials [S][64] | segment ids [S][32] | item lists (gnode_pers64_dev.h)
     const int lr = 4 * w + g, ro = lr * TS + 4 * sub;
+    unsigned* const HI = reinterpret_cast<unsigned*>(HP + (size_t)a.lds_slots * 64);
+    unsigned* const HLmine = HI + (size_t)a.lds_slots * 32 + (size_t)(team * 16 + lr) * PERS_MAX_ITEMS;
     const unsigned lane_b = 16u * sub;
     const unsigned rows = a.rows;
     const unsigned tbytes = (rows + 1u) * 256u;
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
         for (int j = 1; j < NM; ++j)
             if (16 * j + sub < d) m[j] = (base + (unsigned)a.col[start + 16 * j + sub]) * 256u;
     }
+    if (HUBS) pers_hub_stage(a.col, a.segitem, it0, itn, base, HI, HLmine, sub);        // (published by the barrier behind the W staging)
     float4 aS = zero4(), aI = zero4(), aR = zero4();
     float bt = 0.f, gm = 0.f;
     if (valid) {
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
         // ---- A q: the transposed gather (A symmetric: same neighbour lists), ascending column order
         float4 gq = pers_gather<NM, DEPTH>(pers_rsrc(a.Q[cur], tbytes), a.col, base, m, start, end, sub, lane_b, []() {});
         if (HUBS) {
-            pers_hub_partials<DEPTH>(pers_rsrc(a.Q[cur], tbytes), a.col, a.segitem, it0, itn, base, HP, sub, lane_b);
+            pers_hub_partials<DEPTH>(pers_rsrc(a.Q[cur], tbytes), a.col, itn, HI, HLmine, HP, sub, lane_b);
             __syncthreads();
             if (hs0 >= 0) gq = pers_hub_total(HP, hs0, hcnt, sub);
         }
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
 
 // --------------------------------------------------------------------------- host
 static size_t pers_bwd_lds_bytes(int nt, int partial_slots = 128) {
-    const size_t need = sizeof(float) * ((size_t)64 * TS + (size_t)nt * 6 * 16 * TS + (size_t)partial_slots * 64);
+    const size_t need = sizeof(float) * ((size_t)64 * TS + (size_t)nt * 6 * 16 * TS + (size_t)partial_slots * 96 + (size_t)16 * nt * PERS_MAX_ITEMS);
     return std::max<size_t>(need, 84 * 1024);              // > half of the CU's 160 KB: ONE workgroup per CU
 }
 
@@ -277,6 +280,7 @@ int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, 
     const int vi = pl.nt == 1 ? 0 : 1;
     const bool hubs = g->n_hub > 0;
     x.rowhdr = g->rowhdr; x.col = g->col; x.rowmap = g->persmap[vi];
+    x.lds_slots = hubs ? g->perslds[vi] : 0;
     x.hubslot = hubs ? g->pershub[vi] : nullptr; x.segptr = hubs ? g->perssegptr[vi] : nullptr; x.segitem = hubs ? g->perssegitem[vi] : nullptr;
     x.n = g->n; x.B = (int)(rows / g->n); x.rows = (unsigned)rows; x.pp = pers_place_of(pl); x.G = G;
     x.Q[0] = Q0; x.Q[1] = Q1; x.sol = sol; x.keep = keep; x.W = W; x.beta = beta; x.gamma = gamma; x.a = a; x.part = part;

@@ -47,15 +47,16 @@ struct PsBatch {
 template <int K, int NM>
 struct PsBatch<K, 0, NM> { static __device__ __forceinline__ void load(float4*, rsrc_t, const unsigned (&)[NM], unsigned) {} };
 
-// The first wave of loads: batches of 8 slots are issued as far as the longest of the wave's four rows needs (wave-uniform
-// tests: a load instruction costs the CU's texture unit 16 cycles whatever its lanes fetch, and with one workgroup per CU
-// that unit is what a step's gather waits for), at most DEPTH batches in flight; then `under()`, then the sums in slot order.
-template <int J, int DEPTH, int NM, class F>
-struct PsFirst {
+// One WAVE of loads = up to DEPTH batches of 8 slots, starting at batch J0: batches are issued as far as the longest of the
+// wave's four rows needs (wave-uniform tests: a load instruction costs the CU's texture unit 16 cycles whatever its lanes
+// fetch, and with one workgroup per CU that unit is what a step's gather waits for); then `under()`, then the sums in slot
+// order.  v: 8 DEPTH registers.
+template <int J0, int J, int DEPTH, int NM, class F>
+struct PsWave {
     static __device__ __forceinline__ void run(float4& acc, float4* v, int cnt, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b, F& under) {
-        PsBatch<8 * J, 8, NM>::load(v + 8 * J, tab, m, lane_b);
-        if constexpr (J + 1 < DEPTH) {
-            if (__any(cnt > 8 * (J + 1))) { PsFirst<J + 1, DEPTH, NM, F>::run(acc, v, cnt, tab, m, lane_b, under); return; }
+        PsBatch<8 * (J0 + J), 8, NM>::load(v + 8 * J, tab, m, lane_b);
+        if constexpr (J + 1 < DEPTH && 8 * (J0 + J + 1) < 16 * NM) {
+            if (__any(cnt > 8 * (J0 + J + 1))) { PsWave<J0, J + 1, DEPTH, NM, F>::run(acc, v, cnt, tab, m, lane_b, under); return; }
         }
         __builtin_amdgcn_sched_barrier(0);
         under();
@@ -65,25 +66,24 @@ struct PsFirst {
     }
 };
 
-// batches J, J+1, ... NB-1 (8 slots each) of the register-held ids behind the first wave, each behind a wave-uniform test
-template <int J, int NB, int NM>
+// the waves behind the first one, as far as the register-held ids go (each behind a wave-uniform test)
+template <int V, int NV, int DEPTH, int NM>
 struct PsRest {
     static __device__ __forceinline__ void run(float4& acc, int cnt, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b) {
-        if (__any(cnt > 8 * J)) {
-            float4 u[8];
-            PsBatch<8 * J, 8, NM>::load(u, tab, m, lane_b);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { PS_ACC(u[k]) }
-            PsRest<J + 1, NB, NM>::run(acc, cnt, tab, m, lane_b);
+        if (__any(cnt > 8 * DEPTH * V)) {
+            float4 u[8 * DEPTH];
+            auto nothing = []() {};
+            PsWave<DEPTH * V, 0, DEPTH, NM, decltype(nothing)>::run(acc, u, cnt, tab, m, lane_b, nothing);
+            PsRest<V + 1, NV, DEPTH, NM>::run(acc, cnt, tab, m, lane_b);
         }
     }
 };
-template <int NB, int NM>
-struct PsRest<NB, NB, NM> { static __device__ __forceinline__ void run(float4&, int, rsrc_t, const unsigned (&)[NM], unsigned) {} };
+template <int NV, int DEPTH, int NM>
+struct PsRest<NV, NV, DEPTH, NM> { static __device__ __forceinline__ void run(float4&, int, rsrc_t, const unsigned (&)[NM], unsigned) {} };
 
 // AI = sum of the row's neighbour rows of the table behind `tab`, ascending column order (the CPU scatter_add_ order of
-// the reference, ode_nn_ngraph_sim.py:73).  The first 16 NM neighbour ids live in registers (m), longer rows walk the
-// column list.  `under()` runs between the issue of the first wave of loads and its first use: independent work (the
+// the reference, ode_nn_ngraph_sim.py:73), 8 DEPTH rows in flight per lane group.  The first 16 NM neighbour ids live in
+// registers (m: with NM = 6 every row up to the hub threshold), longer rows walk the column list.  `under()` runs between the issue of the first wave of loads and its first use: independent work (the
 // previous step's read-out and streamed stores) travels under the gather's round trip.
 template <int NM, int DEPTH, class F>
 __device__ __forceinline__ float4 pers_gather(rsrc_t tab, const int* __restrict__ col, unsigned base, const unsigned (&m)[NM],
@@ -92,9 +92,9 @@ __device__ __forceinline__ float4 pers_gather(rsrc_t tab, const int* __restrict_
     const int cnt = end - start;
     {
         float4 v[8 * DEPTH];
-        PsFirst<0, DEPTH, NM, F>::run(acc, v, cnt, tab, m, lane_b, under);
+        PsWave<0, 0, DEPTH, NM, F>::run(acc, v, cnt, tab, m, lane_b, under);
     }
-    PsRest<DEPTH, NM * 2, NM>::run(acc, cnt, tab, m, lane_b);
+    PsRest<1, (2 * NM + DEPTH - 1) / DEPTH, DEPTH, NM>::run(acc, cnt, tab, m, lane_b);
     if (__any(cnt > NM * 16)) {
         for (int e0 = start + NM * 16; e0 < end; e0 += 16) {
             const int c2 = end - e0;
@@ -148,17 +148,31 @@ __device__ __forceinline__ bool pers_wait(unsigned* flags, int wgs, unsigned epo
 // a hub's <= 32-edge segments are summed by lane groups of ITS OWN workgroup (the plan's work lists), partials through LDS --
 // the same segments, the same ascending sums and the same segment-order total as k_hub_seg + the consumers of the per-step
 // kernels, so the bits agree, and no second group barrier is needed.  This lane group's items: [it0, it0 + itn).
+#define PERS_MAX_ITEMS 8                               // segment sums one lane group may be given (plan-time bound)
+// LDS behind the tiles (S = the plan's partial slots per workgroup): partials [S][64] floats | neighbour ids of every segment
+// as table byte offsets [S][32] | per lane group its items [PERS_MAX_ITEMS] as (slot | edges << 16).  The ids and item lists
+// are loop-invariant: staged once per sample, so a segment sum is ONE round trip per step (32 rows in flight where the
+// registers allow), not descriptor -> column ids -> rows.
+__device__ __forceinline__ size_t pers_hub_lds_floats(int S, int lane_groups) { return (size_t)S * 96 + (size_t)lane_groups * PERS_MAX_ITEMS; }
+__device__ __forceinline__ void pers_hub_stage(const int* __restrict__ col, const int* __restrict__ items, int it0, int itn, unsigned base,
+                                               unsigned* __restrict__ HI, unsigned* __restrict__ HLmine, int sub) {
+    for (int t = 0; t < itn; ++t) {
+        const int* it = items + 4 * (size_t)(it0 + t);
+        const int lo = it[0], cnt = it[1] - lo, slot = it[2];
+        HI[slot * 32 + sub] = (sub < cnt) ? (base + (unsigned)col[lo + sub]) * 256u : PS_OOB;
+        HI[slot * 32 + 16 + sub] = (16 + sub < cnt) ? (base + (unsigned)col[lo + 16 + sub]) * 256u : PS_OOB;
+        if (sub == 0) HLmine[t] = (unsigned)slot | ((unsigned)cnt << 16);
+    }
+}
 template <int DEPTH>
-__device__ __forceinline__ void pers_hub_partials(rsrc_t tab, const int* __restrict__ col, const int* __restrict__ items, int it0, int itn,
-                                                  unsigned base, float* __restrict__ P, int sub, unsigned lane_b) {
+__device__ __forceinline__ void pers_hub_partials(rsrc_t tab, const int* __restrict__ col, int itn, const unsigned* __restrict__ HI,
+                                                  const unsigned* __restrict__ HLmine, float* __restrict__ P, int sub, unsigned lane_b) {
     for (int t = 0; __any(t < itn); ++t) {
-        int lo = 0, hi = 0, slot = 0;
-        if (t < itn) { const int* it = items + 4 * (size_t)(it0 + t); lo = it[0]; hi = it[1]; slot = it[2]; }
-        const int cnt = hi - lo;
-        unsigned ms[2];
-        ms[0] = (sub < cnt) ? (base + (unsigned)col[lo + sub]) * 256u : PS_OOB;
-        ms[1] = (16 + sub < cnt) ? (base + (unsigned)col[lo + 16 + sub]) * 256u : PS_OOB;
-        const float4 part = pers_gather<2, DEPTH>(tab, col, base, ms, 0, cnt, sub, lane_b, []() {});
+        int cnt = 0, slot = 0;
+        if (t < itn) { const unsigned d = HLmine[t]; slot = (int)(d & 0xFFFFu); cnt = (int)(d >> 16); }
+        unsigned ms[2] = {PS_OOB, PS_OOB};
+        if (t < itn) { ms[0] = HI[slot * 32 + sub]; ms[1] = HI[slot * 32 + 16 + sub]; }
+        const float4 part = pers_gather<2, DEPTH>(tab, col, 0u, ms, 0, cnt, sub, lane_b, []() {});
         if (t < itn) *reinterpret_cast<float4*>(P + (size_t)slot * 64 + 4 * sub) = part;
     }
 }

@@ -33,19 +33,22 @@ def ev_time(fn, reps=REPS):
 
 
 def main():
-    shapes = [("fb-social", 1893, 13835, (1, 2, 4, 8)), ("wiki-vote", 7066, 100736, (1, 2)), ("er-600", 600, 2400, (1, 8, 32))]
+    shapes = [("fb-social", 1893, 13835, (1, 2, 4, 8), 0.0), ("wiki-vote", 7066, 100736, (1, 2), 0.0), ("er-600", 600, 2400, (1, 8, 32), 0.0),
+              ("fb-social-tail", 1893, 13835, (1, 8), 0.8), ("wiki-vote-tail", 7066, 100736, (1, 2), 0.5)]
+    if "--tail" in sys.argv:
+        shapes = shapes[3:]
     maxTime, deltaT = 30, 0.5
     dts = ops.step_sizes(ops.time_grid(maxTime, deltaT))
     rows_out = ops.subsample_rows(maxTime, deltaT)
-    for name, n, m, Bs in shapes:
-        rp, ci = synth.er_csr(n, m, seed=0)
+    for name, n, m, Bs, tail in shapes:
+        rp, ci = synth.heavy_tail_csr(n, m, tail, seed=0) if tail else synth.er_csr(n, m, seed=0)
         g = DeviceGraph(rp, ci)
         P = {k: torch.from_numpy(v).to(dev) for k, v in synth.linear_params(64, seed=0).items()}
         for B in Bs:
             x = torch.from_numpy(synth.samples(n, B, 64, seed=1)).to(dev).reshape(B * n, 67)
             path, plan = ops.forward_path(g, B * n, 64, len(dts))
             ws = torch.empty(ops._lib.load().gnode_forward_workspace_bytes(g.handle, B * n, 64, 0), dtype=torch.uint8, device=dev)
-            out = {"case": name, "n": n, "B": B, "steps": len(dts), "path": path, "plan(nt,wgs,span,gpx,conc)": plan}
+            out = {"case": name, "n": n, "max_degree": int(np.diff(rp).max()), "B": B, "steps": len(dts), "path": path, "plan(nt,wgs,span,gpx,conc)": plan}
             emit = np.asarray([len(dts)], dtype=np.int32) if "--last-only" in sys.argv else None     # read-out at the last grid point only
             for persist in (False, True):
                 t = ev_time(lambda: ops.forward(g, x, P, dts, "euler", emit, workspace=ws, persist=persist))
