@@ -880,9 +880,8 @@ extern "C" int gnode_forward_phase_ticks(int64_t rows, int32_t H, int32_t method
     return 0;
 }
 
-extern "C" int gnode_forward_status(gnode_graph_t g, int64_t rows, int32_t H, int32_t method, const void* workspace, void* stream,
-                                    int32_t* code_host) {
-    GN_CHECK_ARG(g && workspace && code_host, "gnode_forward_status: null pointer");
+extern "C" int gnode_forward_status(int64_t rows, int32_t H, int32_t method, const void* workspace, void* stream, int32_t* code_host) {
+    GN_CHECK_ARG(workspace && code_host && rows > 0, "gnode_forward_status: null pointer");
     *code_host = 0;
     if (H != 64) return 0;
     unsigned err[2] = {0, 0};

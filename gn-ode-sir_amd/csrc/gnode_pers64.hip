@@ -37,17 +37,21 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
     constexpr int STAUX = SC1ST ? 16 : 0;
     // registers: one workgroup per CU, so 256 / 512 / 1024 threads leave 512 / 256 / 128 VGPRs per lane
     constexpr int NM = 6;                                  // neighbour-id registers (16 ids each): every row up to the hub threshold (96)
+    static_assert(16 * NM >= GN_HUB_T, "the id registers must cover every non-hub row");
 #ifndef GN_PERS_DEPTH
 #define GN_PERS_DEPTH 4
 #endif
-    constexpr int DEPTH = NT == 4 ? 1 : GN_PERS_DEPTH;     // batches of 8 neighbour rows in flight per lane group
-    constexpr int O_W = 0, O_W3 = O_W + 64 * TS, O_T = O_W3 + 256, TEAM_F = 4 * 16 * TS;
+    constexpr int DEPTH = NT == 4 ? 1 : (PRJ ? GN_PERS_DEPTH : 3);   // batches of 8 neighbour rows in flight per lane group (training: more state)
+    constexpr int O_W = 0, O_W3 = O_W + 64 * TS, O_HD = O_W3 + 256, O_T = O_HD + 16, TEAM_F = 4 * 16 * TS;   // O_HD: b3[4] | w2[4] | b2
     extern __shared__ __attribute__((aligned(16))) float L[];
     __shared__ unsigned sh[4];
-    const int team = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    const int lane = tid & 63, w = tid >> 6, g = lane >> 4, sub = lane & 15;
+    // (team and wave index are wave-uniform: pinned to SGPRs, so that the LDS tile addresses derived from them are scalars)
+    const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), tid = threadIdx.x & 255;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, sub = lane & 15;
     if (team == 0) load_W_to_lds<false>(a.W, L + O_W);
     if (threadIdx.x < 256) L[O_W3 + threadIdx.x] = a.w3[threadIdx.x];
+    if (threadIdx.x < 4) { L[O_HD + threadIdx.x] = a.b3[threadIdx.x]; L[O_HD + 4 + threadIdx.x] = a.w2[threadIdx.x]; }
+    if (threadIdx.x == 4) L[O_HD + 8] = a.b2[0];
     int gl, idx;                                           // concurrent group, workgroup inside the group
     if (!pers_place(a.pp, a.ctl, sh, gl, idx)) return;
     unsigned* const flags = a.ctl->flags + (size_t)gl * a.pp.fstride;
@@ -106,6 +110,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
             for (int j = 1; j < NM; ++j)
                 if (16 * j + sub < d) m[j] = (base + (unsigned)a.col[start + 16 * j + sub]) * 256u;
         }
+        const int nbt = pers_batches<NM>(end - start);
         if (HUBS) pers_hub_stage(a.col, a.segitem, it0, itn, base, HI, HLmine, sub);    // (the barriers below publish it)
         float4 ys = zero4(), yi = zero4(), yr = zero4(), pr = zero4(), zi = zero4();
         float nb = 0.f, gm = 0.f;
@@ -123,26 +128,31 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
 
         // outputs of step j (trajectory point j+1, kept activations of grid point j, read-out at grid point j+1): nothing in
         // the launch consumes them, so they are issued UNDER the next step's gather (or after the last step)
+        // (their base pointers are pinned to VGPRs: as wave-uniform values the compiler keeps them and every product of the
+        //  grid index with the slab size in SGPRs, spills those, and a kernel with scratch cannot be captured on first use)
+        const float* solv = a.sol; const float* keepv = a.keep;
+        float* Sv = a.S; float* Iv = a.I; float* Rv = a.R;
+        asm volatile("" : "+v"(solv), "+v"(keepv), "+v"(Sv), "+v"(Iv), "+v"(Rv));
         auto outputs = [&](int j) {
             if (!PRJ && valid) {
-                if (a.sol) {
-                    float* sn = a.sol + (size_t)(j + 1) * 4 * slab;
-                    st4so<true>(sn, off, ys); st4so<true>(sn + slab, off, yi); st4so<true>(sn + 2 * slab, off, yr);
+                if (solv) {
+                    float* sn = const_cast<float*>(solv) + ((size_t)(j + 1) * 4 * slab + (size_t)row * 64 + 4 * sub);
+                    st4s<true>(sn, ys); st4s<true>(sn + slab, yi); st4s<true>(sn + 2 * slab, yr);
                     if (j >= 1) {
-                        if (a.keep) st4so<true>(gn_keep_ps(a.keep, rows, j), off, ai_k);
-                        else st4so<true>(a.sol + (size_t)j * 4 * slab + 3 * slab, off, ai_k);
+                        if (keepv) st4s<true>(const_cast<float*>(keepv) + ((size_t)(3 * j + 2) * gn_keep_stride(rows) + (size_t)row * 64 + 4 * sub), ai_k);
+                        else st4s<true>(const_cast<float*>(solv) + ((size_t)j * 4 * slab + 3 * slab + (size_t)row * 64 + 4 * sub), ai_k);
                     }
                 }
-                if (a.keep) st4so<true>(gn_keep_zs(a.keep, rows, j), off, zs_k);
+                if (keepv) st4s<true>(const_cast<float*>(keepv) + ((size_t)(3 * j) * gn_keep_stride(rows) + (size_t)row * 64 + 4 * sub), zs_k);
             }
             const int slot = a.sched.slot[j];
             if (slot >= 0) {
                 float pS, pI, pR;
                 const float prj[4] = {pr.x, pr.y, pr.z, pr.w};
-                readout64<PRJ>(ys, yi, yr, prj, sub, w3s, a.b3, a.w2, a.b2, pS, pI, pR);
+                readout64<PRJ>(ys, yi, yr, prj, sub, w3s, L + O_HD, L + O_HD + 4, L + O_HD + 8, pS, pI, pR);
                 if (valid && sub == 0) {
                     const size_t o = (size_t)slot * rows + row;
-                    a.S[o] = pS; a.I[o] = pI; a.R[o] = pR;
+                    Sv[o] = pS; Iv[o] = pI; Rv[o] = pR;
                 }
             }
         };
@@ -162,10 +172,12 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
             PS_STAMP(0)
             const float4 zs = *reinterpret_cast<const float4*>(T2S + ro);      // Z_S(y_k): the matrix phase behind the last flag
             // ---- gather (step k-1's outputs under its round trip) + SIR update (ode_nn_ngraph_sim.py:75-77) + Euler step
-            float4 acc = pers_gather<NM, DEPTH>(pers_rsrc(tab_cur, tbytes), a.col, base, m, start, end, sub, lane_b,
-                                                [&]() { if (k > 0) outputs(k - 1); });
+            // (1024-thread workgroups: the read-out's temporaries next to 32 registers of loads in flight do not fit 128
+            //  VGPRs -- spills, and a kernel with scratch cannot be captured on first use -- so there it runs in front)
+            if (NT == 4 && k > 0) outputs(k - 1);
+            float4 acc = pers_gather<NM, DEPTH>(pers_rsrc(tab_cur, tbytes), m, nbt, lane_b, [&]() { if (NT < 4 && k > 0) outputs(k - 1); });
             if (HUBS) {
-                pers_hub_partials<(NT == 4 ? 1 : 4)>(pers_rsrc(tab_cur, tbytes), a.col, itn, HI, HLmine, HP, sub, lane_b);
+                pers_hub_partials<(NT == 4 ? 1 : 4)>(pers_rsrc(tab_cur, tbytes), itn, HI, HLmine, HP, sub, lane_b);
                 __syncthreads();
                 if (hs0 >= 0) acc = pers_hub_total(HP, hs0, hcnt, sub);
             }
@@ -351,7 +363,7 @@ bool gn_pers64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p) {
 size_t gn_pers64_ctl_bytes() { return gn_align(sizeof(PersCtl)); }
 
 static size_t pers_lds_bytes(int nt, int partial_slots = PERS_MAX_PARTIALS) {
-    const size_t need = sizeof(float) * ((size_t)64 * TS + 256 + (size_t)nt * 4 * 16 * TS + (size_t)partial_slots * 96 + (size_t)16 * nt * PERS_MAX_ITEMS);
+    const size_t need = sizeof(float) * ((size_t)64 * TS + 256 + 16 + (size_t)nt * 4 * 16 * TS + (size_t)partial_slots * 96 + (size_t)16 * nt * PERS_MAX_ITEMS);
     return std::max<size_t>(need, 84 * 1024);              // > half of the CU's 160 KB: ONE workgroup per CU
 }
 

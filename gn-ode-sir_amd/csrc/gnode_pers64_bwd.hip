@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
         for (int j = 1; j < NM; ++j)
             if (16 * j + sub < d) m[j] = (base + (unsigned)a.col[start + 16 * j + sub]) * 256u;
     }
+    const int nbt = pers_batches<NM>(end - start);
     if (HUBS) pers_hub_stage(a.col, a.segitem, it0, itn, base, HI, HLmine, sub);        // (published by the barrier behind the W staging)
     float4 aS = zero4(), aI = zero4(), aR = zero4();
     float bt = 0.f, gm = 0.f;
@@ -149,9 +150,9 @@ __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
             if (sh[2] == 0u) return;
         }
         // ---- A q: the transposed gather (A symmetric: same neighbour lists), ascending column order
-        float4 gq = pers_gather<NM, DEPTH>(pers_rsrc(a.Q[cur], tbytes), a.col, base, m, start, end, sub, lane_b, []() {});
+        float4 gq = pers_gather<NM, DEPTH>(pers_rsrc(a.Q[cur], tbytes), m, nbt, lane_b, []() {});
         if (HUBS) {
-            pers_hub_partials<DEPTH>(pers_rsrc(a.Q[cur], tbytes), a.col, itn, HI, HLmine, HP, sub, lane_b);
+            pers_hub_partials<DEPTH>(pers_rsrc(a.Q[cur], tbytes), itn, HI, HLmine, HP, sub, lane_b);
             __syncthreads();
             if (hs0 >= 0) gq = pers_hub_total(HP, hs0, hcnt, sub);
         }

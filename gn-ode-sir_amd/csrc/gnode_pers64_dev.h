@@ -48,68 +48,71 @@ template <int K, int NM>
 struct PsBatch<K, 0, NM> { static __device__ __forceinline__ void load(float4*, rsrc_t, const unsigned (&)[NM], unsigned) {} };
 
 // One WAVE of loads = up to DEPTH batches of 8 slots, starting at batch J0: batches are issued as far as the longest of the
-// wave's four rows needs (wave-uniform tests: a load instruction costs the CU's texture unit 16 cycles whatever its lanes
-// fetch, and with one workgroup per CU that unit is what a step's gather waits for); then `under()`, then the sums in slot
-// order.  v: 8 DEPTH registers.
-template <int J0, int J, int DEPTH, int NM, class F>
-struct PsWave {
-    static __device__ __forceinline__ void run(float4& acc, float4* v, int cnt, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b, F& under) {
-        PsBatch<8 * (J0 + J), 8, NM>::load(v + 8 * J, tab, m, lane_b);
-        if constexpr (J + 1 < DEPTH && 8 * (J0 + J + 1) < 16 * NM) {
-            if (__any(cnt > 8 * (J0 + J + 1))) { PsWave<J0, J + 1, DEPTH, NM, F>::run(acc, v, cnt, tab, m, lane_b, under); return; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        under();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 8 * (J + 1); ++k) { PS_ACC(v[k]) }
+// wave's four rows needs (wave-uniform count nb: a load instruction costs the CU's texture unit 16 cycles whatever its lanes
+// fetch, and with one workgroup per CU that unit is what a step's gather waits for); then `under()` -- ONE copy of it --,
+// then the sums in slot order.  Registers of batches that were not issued are never read (same nb on both sides).
+template <int J0, int J, int NB, int NM>
+struct PsIssue {
+    static __device__ __forceinline__ void run(float4* v, int nb, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b) {
+        if (J == 0 || nb > J) PsBatch<8 * (J0 + J), 8, NM>::load(v + 8 * J, tab, m, lane_b);
+        PsIssue<J0, J + 1, NB, NM>::run(v, nb, tab, m, lane_b);
     }
 };
+template <int J0, int NB, int NM>
+struct PsIssue<J0, NB, NB, NM> { static __device__ __forceinline__ void run(float4*, int, rsrc_t, const unsigned (&)[NM], unsigned) {} };
 
-// the waves behind the first one, as far as the register-held ids go (each behind a wave-uniform test)
+template <int J0, int DEPTH, int NM, class F>
+__device__ __forceinline__ void ps_wave(float4& acc, int nbt, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b, F& under) {
+    constexpr int NB = (2 * NM - J0) < DEPTH ? (2 * NM - J0) : DEPTH;      // batches this wave can hold ids for
+    float4 v[8 * NB];
+    const int nb = nbt - J0;                                               // batches of this wave the longest row needs (>= 1)
+    PsIssue<J0, 0, NB, NM>::run(v, nb, tab, m, lane_b);
+    __builtin_amdgcn_sched_barrier(0);
+    under();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        if (j == 0 || nb > j) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { PS_ACC(v[8 * j + k]) }
+        }
+}
+
+// the waves behind the first one, as far as the register-held ids go
 template <int V, int NV, int DEPTH, int NM>
 struct PsRest {
-    static __device__ __forceinline__ void run(float4& acc, int cnt, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b) {
-        if (__any(cnt > 8 * DEPTH * V)) {
-            float4 u[8 * DEPTH];
+    static __device__ __forceinline__ void run(float4& acc, int nbt, rsrc_t tab, const unsigned (&m)[NM], unsigned lane_b) {
+        if (nbt > DEPTH * V) {
             auto nothing = []() {};
-            PsWave<DEPTH * V, 0, DEPTH, NM, decltype(nothing)>::run(acc, u, cnt, tab, m, lane_b, nothing);
-            PsRest<V + 1, NV, DEPTH, NM>::run(acc, cnt, tab, m, lane_b);
+            ps_wave<DEPTH * V, DEPTH, NM>(acc, nbt, tab, m, lane_b, nothing);
+            PsRest<V + 1, NV, DEPTH, NM>::run(acc, nbt, tab, m, lane_b);
         }
     }
 };
 template <int NV, int DEPTH, int NM>
 struct PsRest<NV, NV, DEPTH, NM> { static __device__ __forceinline__ void run(float4&, int, rsrc_t, const unsigned (&)[NM], unsigned) {} };
 
+// batches of 8 neighbour slots the longest of the wave's four rows needs (wave-uniform, >= 1).  A row's length never changes:
+// callers compute it ONCE per sample -- tested inside the step loop, each of the 2 NM thresholds becomes a loop-invariant
+// 64-bit mask the compiler keeps live in SGPRs across the whole integration.
+template <int NM>
+__device__ __forceinline__ int pers_batches(int cnt) {
+    int nbt = 1;
+#pragma unroll
+    for (int j = 1; j < 2 * NM; ++j) nbt += __any(cnt > 8 * j) ? 1 : 0;
+    return __builtin_amdgcn_readfirstlane(nbt);
+}
+
 // AI = sum of the row's neighbour rows of the table behind `tab`, ascending column order (the CPU scatter_add_ order of
-// the reference, ode_nn_ngraph_sim.py:73), 8 DEPTH rows in flight per lane group.  The first 16 NM neighbour ids live in
-// registers (m: with NM = 6 every row up to the hub threshold), longer rows walk the column list.  `under()` runs between the issue of the first wave of loads and its first use: independent work (the
-// previous step's read-out and streamed stores) travels under the gather's round trip.
+// the reference, ode_nn_ngraph_sim.py:73), 8 DEPTH rows in flight per lane group.  All of the row's neighbour ids live in
+// registers (m: 16 NM >= the hub threshold; a hub row's own gather is empty, a segment has 32).  `under()` runs between
+// the issue of the first wave of loads and its first use: independent work (the previous step's read-out and streamed
+// stores) travels under the gather's round trip.  nbt: pers_batches() of the row lengths.
 template <int NM, int DEPTH, class F>
-__device__ __forceinline__ float4 pers_gather(rsrc_t tab, const int* __restrict__ col, unsigned base, const unsigned (&m)[NM],
-                                              int start, int end, int sub, unsigned lane_b, F&& under) {
+__device__ __forceinline__ float4 pers_gather(rsrc_t tab, const unsigned (&m)[NM], int nbt, unsigned lane_b, F&& under) {
     float4 acc = zero4();
-    const int cnt = end - start;
-    {
-        float4 v[8 * DEPTH];
-        PsWave<0, 0, DEPTH, NM, F>::run(acc, v, cnt, tab, m, lane_b, under);
-    }
-    PsRest<1, (2 * NM + DEPTH - 1) / DEPTH, DEPTH, NM>::run(acc, cnt, tab, m, lane_b);
-    if (__any(cnt > NM * 16)) {
-        for (int e0 = start + NM * 16; e0 < end; e0 += 16) {
-            const int c2 = end - e0;
-            const unsigned mm[1] = {(sub < c2) ? (base + (unsigned)col[e0 + sub]) * 256u : PS_OOB};
-            float4 u[8];
-            PsBatch<0, 8, 1>::load(u, tab, mm, lane_b);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { PS_ACC(u[k]) }
-            if (__any(c2 > 8)) {
-                PsBatch<8, 8, 1>::load(u, tab, mm, lane_b);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { PS_ACC(u[k]) }
-            }
-        }
-    }
+    ps_wave<0, DEPTH, NM>(acc, nbt, tab, m, lane_b, under);
+    PsRest<1, (2 * NM + DEPTH - 1) / DEPTH, DEPTH, NM>::run(acc, nbt, tab, m, lane_b);
     return acc;
 }
 
@@ -165,14 +168,14 @@ __device__ __forceinline__ void pers_hub_stage(const int* __restrict__ col, cons
     }
 }
 template <int DEPTH>
-__device__ __forceinline__ void pers_hub_partials(rsrc_t tab, const int* __restrict__ col, int itn, const unsigned* __restrict__ HI,
+__device__ __forceinline__ void pers_hub_partials(rsrc_t tab, int itn, const unsigned* __restrict__ HI,
                                                   const unsigned* __restrict__ HLmine, float* __restrict__ P, int sub, unsigned lane_b) {
     for (int t = 0; __any(t < itn); ++t) {
         int cnt = 0, slot = 0;
         if (t < itn) { const unsigned d = HLmine[t]; slot = (int)(d & 0xFFFFu); cnt = (int)(d >> 16); }
         unsigned ms[2] = {PS_OOB, PS_OOB};
         if (t < itn) { ms[0] = HI[slot * 32 + sub]; ms[1] = HI[slot * 32 + 16 + sub]; }
-        const float4 part = pers_gather<2, DEPTH>(tab, col, 0u, ms, 0, cnt, sub, lane_b, []() {});
+        const float4 part = pers_gather<2, DEPTH>(tab, ms, pers_batches<2>(cnt), lane_b, []() {});
         if (t < itn) *reinterpret_cast<float4*>(P + (size_t)slot * 64 + 4 * sub) = part;
     }
 }

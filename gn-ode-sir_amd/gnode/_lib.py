@@ -72,7 +72,7 @@ def load():
     lib.gnode_forward_keep_bytes.argtypes = [vp, i64, i32, i32, i32]
     lib.gnode_forward_keep_bytes.restype = sz
     lib.gnode_forward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, sz, i64, i32, vp, sz, vp, i32, C.POINTER(i32)]
-    lib.gnode_forward_status.argtypes = [vp, i64, i32, i32, vp, vp, C.POINTER(i32)]
+    lib.gnode_forward_status.argtypes = [i64, i32, i32, vp, vp, C.POINTER(i32)]
     lib.gnode_forward_status.restype = C.c_int
     lib.gnode_forward_path.argtypes = [vp, i64, i32, i32, i32, i32, i32, i32, C.POINTER(i32)]
     lib.gnode_forward_path.restype = C.c_int

@@ -124,7 +124,8 @@ def forward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarray
     if sol is not None:
         sol.gnode_keep = keep
         sol.gnode_info = int(info.value)         # what the call left in sol / keep: the backward checks the pairing
-    forward.last_workspace = (graph, rows, H, m, ws, n_steps, n_out, sol is not None, persist)
+    # (no reference to `graph` is kept: a DeviceGraph released while some stream is capturing would hipFree inside the capture)
+    forward.last_workspace = (rows, H, m, ws, forward_path(graph, rows, H, n_steps, n_out, sol is not None, method, persist)[0])
     return out[0], out[1], out[2], sol
 
 
@@ -140,11 +141,11 @@ def forward_path(graph: DeviceGraph, rows: int, H: int, n_steps: int, n_out: int
 
 def forward_status() -> int:
     """0, or the give-up code of the persistent launch behind the LAST `forward` call (synchronises the stream)."""
-    graph, rows, H, m, ws, n_steps, n_out, want_sol, persist = forward.last_workspace
-    if forward_path(graph, rows, H, n_steps, n_out, want_sol, "euler" if m == 0 else "rk4", persist)[0] != 2:
+    rows, H, m, ws, path = forward.last_workspace
+    if path != 2:
         return 0                                 # (the control block is only written by the persistent launch)
     code = C.c_int32(0)
-    _lib.check(_lib.load().gnode_forward_status(graph.handle, rows, H, m, _lib.ptr(ws), _lib.stream_ptr(), C.byref(code)))
+    _lib.check(_lib.load().gnode_forward_status(rows, H, m, _lib.ptr(ws), _lib.stream_ptr(), C.byref(code)))
     return int(code.value)
 
 
