@@ -18,8 +18,15 @@ Besides the contract's keys the JSON line carries (rank 0, N = 1 only; none of i
   roofline      the step kernel against the memory system, several honest views (see `roofline_views`)
   cpu_baseline  the reference's op sequence in PyTorch-CPU + the C/OpenMP restatement, timed on the host cores,
                 and the check of the TIMED GPU outputs against that C restatement (`outputs_checked`)
-  train         forward + adjoint backward + Adam, ms per step, on configs[1]'s shape and on the 75k graph x 4
+  train         forward + adjoint backward + Adam, ms per step, on configs[1]'s shape and on the 75k graph x 4, each with a
+                gradient check (default path vs the recomputing per-interval path; configs[1]: vs the reference-class fixture)
+  mid           the reference's REAL regime (monitorer-sim.py:10: batch_size 1; fb-social / wiki-vote sizes) on graphs with
+                those datasets' degree tails: forward and training step at B = 1, persistent one-launch path vs one launch
+                per Euler step
+  h8            configs[4]'s shape (monitorer-ngraphs.py:20: hidden 8): training step on a concatenated batch of 8 graphs
+                of the five training sizes, evaluation forward on 8 x 75k nodes, kernel averages and byte fractions
   sir           the Monte-Carlo label generator on configs[2]'s shape (10 000 sims x T = 20)
+With --gpus N > 1 the line keeps `roofline` (rank 0's kernel) and adds every rank's elapsed time (`rank_elapsed_s`).
 """
 import argparse
 import json
@@ -127,28 +134,228 @@ def bench_train(lib, dev, n, m, B, H, maxTime, deltaT, reps):
     bwd_ms, bwd_n = prof_read(lib, 2)
     lib.gnode_profile_enable(0)
     n_steps = len(ops.time_grid(maxTime, deltaT)) - 1
+    path = ops.forward_path(model.odefunc.graph, B * n, H, n_steps, len(rows), want_sol=True)[0]
     out = {"shape": f"ER n={n} nnz={nnz} B={B} H={H} {n_steps} Euler steps", "ms_per_step": dt * 1e3,
-           "node_timesteps_per_s": B * n * n_steps / dt, "loss_finite": bool(torch.isfinite(loss).item()),
-           "fwd_step_kernel_avg_us": fwd_ms / max(fwd_n, 1) * 1e3, "bwd_interval_kernel_avg_us": bwd_ms / max(bwd_n, 1) * 1e3}
-    if bwd_n:
-        # backward interval kernel (k_bwd_kept64, both instances averaged), one sample-interval: DESIGN.md section 7
-        sb = bwd_interval_bytes(n, nnz, H)
-        for k in ("algorithmic", "compulsory"):
-            out[f"bwd_{k}_bytes_per_launch"] = sb[k] * B
-            out[f"bwd_{k}_frac_of_hbm_peak"] = sb[k] * B / (bwd_ms / bwd_n * 1e-3) / 1e9 / HBM_PEAK_GBS
-        # measured L2<->fabric traffic of the training kernels, from the committed PMC passes (same provenance rules as the
-        # step kernel's: a file, labelled as such)
-        pm = os.path.join(ROOT, "profiles", "pmc_train_latest.json")
-        if os.path.exists(pm) and (n, nnz, B, H, maxTime) == (75000, 1000000, 4, 64, 30):
+           "node_timesteps_per_s": B * n * n_steps / dt, "loss_finite": bool(torch.isfinite(loss).item())}
+    if path == 2:
+        # one persistent launch per forward / per adjoint sweep (intervals n_steps-1 .. 1; the last interval is its own launch)
+        out["fwd_launch_avg_us (all %d Euler steps)" % n_steps] = fwd_ms / max(fwd_n, 1) * 1e3
+        out["bwd_launch_avg_us (%d intervals; 2 launches when the batch exceeds one resident grid)" % (n_steps - 1)] = bwd_ms / max(bwd_n, 1) * 1e3
+        out["fwd_us_per_euler_step"] = fwd_ms / max(fwd_n, 1) * 1e3 / n_steps
+        if fwd_n:
+            sbf = step_bytes(n, nnz, H, False)
+            out["fwd_algorithmic_frac_of_hbm_peak"] = sbf["algorithmic"] * B * n_steps / (fwd_ms / fwd_n * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["limiter"] = "latency: one group barrier (~2 us of flag flight) and one gather round trip (~1 us) per step; see DESIGN.md section 4.2"
+        bwd_n = 0
+    else:
+        out["fwd_step_kernel_avg_us"] = fwd_ms / max(fwd_n, 1) * 1e3
+        out["bwd_interval_kernel_avg_us"] = bwd_ms / max(bwd_n, 1) * 1e3
+    out["path"] = {0: "one launch per Euler step", 1: "one-workgroup launch", 2: "persistent one-launch"}[path]
+    # gradient check (not timed): the default path (kept activations; persistent launches where they apply) against the
+    # recomputing backward behind one launch per Euler step / interval, same weights, same batch
+    try:
+        model.load_state_dict({**model.state_dict(), **{k: torch.from_numpy(v) for k, v in P.items()}})
+        grads = []
+        for keep, persist in ((None, None), (False, False)):
+            old = (ops.KEEP_DEFAULT, ops.PERSIST_DEFAULT)
+            if keep is not None: ops.KEEP_DEFAULT, ops.PERSIST_DEFAULT = keep, persist
             try:
-                d = json.load(open(pm))
-                out["measured_fabric_traffic_bytes_per_launch"] = {k.replace("void ", ""): v["traffic_bytes_per_launch"]
-                                                                   for k, v in d["kernels"].items()}
-                out["traffic_source"] = {"file": "profiles/pmc_train_latest.json", "measured_in_this_run": False,
-                                         "collected": d.get("collected"), "tree": d.get("tree")}
-            except Exception:
-                pass
+                model.zero_grad()
+                S, I, R = model(x, out_rows=rows)
+                (l1_loss_sum(S, I, R, y, 1) / (B * n * (maxTime - 1) * 3)).backward()
+                grads.append({k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None})
+            finally:
+                ops.KEEP_DEFAULT, ops.PERSIST_DEFAULT = old
+        rel = {k: float((grads[0][k] - grads[1][k]).abs().max() / (grads[1][k].abs().max() + 1e-30)) for k in grads[0] if k != "linearS2.bias"}
+        out["gradient_check"] = {"default_vs_recomputing_per_interval_max_rel": max(rel.values()), "worst": max(rel, key=rel.get),
+                                 "pass": bool(max(rel.values()) <= 2e-4), "gW_checksum": float(grads[0]["odefunc.linear.weight"].double().sum().item())}
+    except Exception as exc:
+        out["gradient_check"] = f"unavailable: {type(exc).__name__}: {exc}"
     del model, x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+def reference_fixture_gradient(dev):
+    """configs[1]'s shape, B = 1, the full 59-interval horizon: the product's training gradient against the one the
+    REFERENCE's classes produced in float64 (tests/golden/adjoint_fb_H64_T30.npz: data only, written by
+    tests/golden/make_golden_adjoint.py in the build container)."""
+    import scipy.sparse as sp
+    import torch
+    from gnode import ops, synth
+    from gnode.autograd import l1_loss_sum
+    from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from labels import closed_form_labels
+    d = dict(np.load(os.path.join(ROOT, "tests", "golden", "adjoint_fb_H64_T30.npz")))
+    n, B, H, maxTime, deltaT = int(d["n"]), int(d["B"]), int(d["H"]), int(d["maxTime"]), float(d["deltaT"])
+    rp, ci = synth.er_csr(n, int(d["m"]), seed=int(d["graph_seed"]))
+    A = sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n))
+    P = synth.linear_params(H, seed=int(d["param_seed"]))
+    model = ODEBlock(maxTime, deltaT, n, [0], H, ODEfunc(A, 0.2, 0.1, H, dev), dev).to(dev)
+    model.load_state_dict({**model.state_dict(), **{k: torch.from_numpy(v) for k, v in P.items()}})
+    x = torch.from_numpy(synth.samples(n, B, H, seed=int(d["sample_seed"]))).to(dev)
+    y = torch.from_numpy(closed_form_labels(B, n, maxTime).reshape(B * n, maxTime, 3)).to(dev)
+    S, I, R = model(x, out_rows=ops.subsample_rows(maxTime, deltaT))
+    loss = l1_loss_sum(S, I, R, y, 1) / (B * n * (maxTime - 1) * 3)
+    loss.backward()
+    rel = {}
+    for k, v in model.named_parameters():
+        if v.grad is None or k == "linearS2.bias" or "G:" + k not in d:
+            continue
+        want = d["G:" + k]
+        rel[k] = float(np.abs(v.grad.cpu().numpy().astype(np.float64) - want).max() / (np.abs(want).max() + 1e-30))
+    return {"fixture": "tests/golden/adjoint_fb_H64_T30.npz (reference ODEBlock / ODEfunc / loss, float64, 59 intervals)",
+            "loss_abs_err": abs(float(loss.item()) - float(d["loss"])), "max_rel_err": max(rel.values()), "worst": max(rel, key=rel.get),
+            "reference_fp32_vs_its_float64_max_rel": max(float(np.abs(d["G32:" + k] - d["G:" + k]).max() / (np.abs(d["G:" + k]).max() + 1e-30)) for k in rel),
+            "pass": bool(max(rel.values()) <= 2e-4)}
+
+
+def _ev_ms(fn, reps, warm=2):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def bench_mid(lib, dev):
+    """The regime the reference actually runs (monitorer-sim.py:10,17-22: batch_size 1 on fb-social / wiki-vote) on graphs with
+    those datasets' degree tails (gnode/synth.py heavy_tail_csr: longest row ~740 / ~1 020): ODEBlock.forward with all 60
+    grid points and one training step at B = 1; the persistent one-launch path (default) next to one launch per step."""
+    import scipy.sparse as sp
+    import torch
+    from gnode import ops, synth
+    from gnode.autograd import l1_loss_sum
+    from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
+    out = {}
+    H, maxTime, deltaT = 64, 30, 0.5
+    n_steps = len(ops.time_grid(maxTime, deltaT)) - 1
+    rows = ops.subsample_rows(maxTime, deltaT)
+    for name, n, m, tail in (("fb-social size, heavy tail", 1893, 13835, 0.8), ("wiki-vote size, heavy tail", 7066, 100736, 0.5)):
+        rp, ci = synth.heavy_tail_csr(n, m, tail, seed=0)
+        nnz = int(ci.shape[0])
+        A = sp.csr_matrix((np.ones(nnz), ci, rp), shape=(n, n))
+        model = ODEBlock(maxTime, deltaT, n, [0], H, ODEfunc(A, 0.2, 0.1, H, dev), dev).to(dev)
+        model.load_state_dict({**model.state_dict(), **{k: torch.from_numpy(v) for k, v in synth.linear_params(H, seed=0).items()}})
+        x = torch.from_numpy(synth.samples(n, 1, H, seed=3)).to(dev)
+        y = torch.from_numpy(np.random.default_rng(0).dirichlet(np.ones(3), size=(n, maxTime))).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+
+        def fwd():
+            with torch.no_grad():
+                model(x)
+
+        def train():
+            opt.zero_grad()
+            S, I, R = model(x, out_rows=rows)
+            (l1_loss_sum(S, I, R, y, 1) / (n * (maxTime - 1) * 3)).backward()
+            opt.step()
+
+        rec = {"n": n, "nnz": nnz, "longest_row": int(np.diff(rp).max()), "B": 1, "euler_steps": n_steps,
+               "plan (tiles per workgroup, workgroups, XCDs per sample, samples per XCD, samples at once)":
+                   ops.forward_path(model.odefunc.graph, n, H, n_steps)[1]}
+        for label, persist in (("persistent", True), ("per_step", False)):
+            old = ops.PERSIST_DEFAULT
+            ops.PERSIST_DEFAULT = persist
+            try:
+                rec[label + "_forward_ms"] = _ev_ms(fwd, 20)
+                rec[label + "_train_step_ms"] = _ev_ms(train, 10)
+            finally:
+                ops.PERSIST_DEFAULT = old
+        rec["persistent_us_per_euler_step"] = rec["persistent_forward_ms"] * 1e3 / n_steps
+        sb = step_bytes(n, nnz, H, True)
+        rec["forward_algorithmic_frac_of_hbm_peak"] = sb["algorithmic"] * n_steps / (rec["persistent_forward_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        rec["limiter"] = "latency: per step one group barrier (~2 us flag flight) + one gather round trip (~1 us) + the hub segments' round trips"
+        out[name] = rec
+        del model, x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_h8(lib, dev):
+    """configs[4]'s shape (monitorer-ngraphs.py:10,20,22: hidden 8, batch_size 8, train on dolphins / fb-food / fb-social /
+    openflights / wiki-vote, evaluate on epinions): a training step on a concatenated batch of 8 graphs of the five training
+    sizes, and the evaluation forward on 8 x 75k nodes (Erdos-Renyi stand-ins of those node / edge counts)."""
+    import scipy.sparse as sp
+    import torch
+    from gnode import ops, synth
+    from gnode import ode_nn_ngraphs as multi
+    from gnode.autograd import l1_loss_sum
+    H, maxTime, deltaT = 8, 20, 0.5                                   # monitorer-ngraphs.py:14,20: maxTime 20
+    n_steps = len(ops.time_grid(maxTime, deltaT)) - 1
+    rows = ops.subsample_rows(maxTime, deltaT)
+    sizes = [(62, 159), (620, 2102), (1893, 13835), (2905, 15645), (7066, 100736), (75000, 500000)]
+    csr = [synth.er_csr(n, m, seed=n) for n, m in sizes]
+    A_list = [sp.csr_matrix((np.ones(c.shape[0]), c, r), shape=(len(r) - 1, len(r) - 1)) for r, c in csr]
+    model = multi.ODEBlock(maxTime, deltaT, H, multi.ODEfunc(A_list, H, dev), dev).to(dev)
+    torch.manual_seed(0)
+
+    def batch(picks):
+        xs = []
+        for j, p in enumerate(picks):
+            xi = synth.samples(sizes[p][0], 1, H, seed=j)[0]
+            xi[0, 5] = p + 1                                          # the graph marker (ode_nn_ngraphs.py:333)
+            xs.append(xi)
+        return torch.from_numpy(np.concatenate(xs, 0)).to(dev)
+
+    out = {}
+    # ---- training step: batch of 8 over the five training graphs
+    x = batch([0, 1, 2, 3, 4, 2, 1, 4])
+    tot = x.shape[0]
+    nnz = sum(int(csr[p][1].shape[0]) for p in [0, 1, 2, 3, 4, 2, 1, 4])
+    y = torch.from_numpy(np.random.default_rng(0).dirichlet(np.ones(3), size=(tot, maxTime))).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+
+    def train():
+        opt.zero_grad()
+        S, I, R = model(x, out_rows=rows)
+        (l1_loss_sum(S, I, R, y, 1) / (tot * (maxTime - 1) * 3)).backward()
+        opt.step()
+
+    train(); train()
+    torch.cuda.synchronize()
+    lib.gnode_profile_enable(1)
+    ms = _ev_ms(train, 10, warm=0)
+    f_ms, f_n = prof_read(lib, 0)
+    b_ms, b_n = prof_read(lib, 2)
+    lib.gnode_profile_enable(0)
+    sb = step_bytes(tot, nnz, H, False)
+    out["train batch of 8 graphs (62..7066 nodes)"] = {
+        "sum_nodes": tot, "nnz": nnz, "H": H, "euler_steps": n_steps, "train_step_ms": ms,
+        "fwd_step_kernel_avg_us (k_step_generic)": f_ms / max(f_n, 1) * 1e3, "bwd_interval_kernel_avg_us (k_bwd_fused_generic)": b_ms / max(b_n, 1) * 1e3,
+        "fwd_algorithmic_frac_of_hbm_peak": (sb["algorithmic"] / (f_ms / f_n * 1e-3) / 1e9 / HBM_PEAK_GBS) if f_n else None,
+        "limiter": "launch latency: 23k rows x 32-byte rows is 2.6 MB of state per step"}
+    del y
+    # ---- evaluation forward: 8 x 75k nodes
+    xe = batch([5] * 8)
+    tot_e, nnz_e = xe.shape[0], 8 * int(csr[5][1].shape[0])
+
+    def fwd():
+        with torch.no_grad():
+            model(xe, out_rows=rows)
+
+    fwd(); fwd()
+    torch.cuda.synchronize()
+    lib.gnode_profile_enable(1)
+    ms_e = _ev_ms(fwd, 5, warm=0)
+    f_ms, f_n = prof_read(lib, 0)
+    lib.gnode_profile_enable(0)
+    sbe = step_bytes(tot_e, nnz_e, H, False)
+    t_l = f_ms / max(f_n, 1) * 1e-3
+    out["evaluation forward 8 x 75k nodes"] = {
+        "sum_nodes": tot_e, "nnz": nnz_e, "H": H, "euler_steps": n_steps, "forward_ms": ms_e, "node_timesteps_per_s": tot_e * n_steps / (ms_e * 1e-3),
+        "step_kernel_avg_us (k_step_generic)": t_l * 1e6,
+        "algorithmic_bytes_per_launch": sbe["algorithmic"], "compulsory_bytes_per_launch": sbe["compulsory"],
+        "algorithmic_frac_of_hbm_peak": sbe["algorithmic"] / t_l / 1e9 / HBM_PEAK_GBS if f_n else None,
+        "compulsory_frac_of_hbm_peak": sbe["compulsory"] / t_l / 1e9 / HBM_PEAK_GBS if f_n else None}
+    del model, x, xe
     torch.cuda.empty_cache()
     return out
 
@@ -286,10 +493,13 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms, step_cnt = prof_read(lib, 0)
     lib.gnode_profile_enable(0)
+    rank_elapsed = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.zeros(world, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t[rank] = elapsed
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)                    # every rank's own clock around the same K steps
+        rank_elapsed = [float(v) for v in t.tolist()]
+        elapsed = max(rank_elapsed)
 
     # sanity on the timed outputs (not timed): probabilities.  The real check (against the C restatement of the
     # reference) is in the cpu_baseline leg below: `outputs_checked`.
@@ -319,7 +529,8 @@ def main():
         "node_maxTime_per_s": world * B * n * args.maxTime * args.steps / elapsed,
         # `frac` is the conservative view: bytes that MUST cross HBM once per launch / launch time / HBM spec peak.  The
         # launch is not bounded by HBM proper (see `limiter`): the other views are listed so that none has to be inferred.
-        "roofline": {"bound": "hbm", "kernel": "k_step64<true> (software-pipelined CSR pull-gather + MFMA node MLPs + SIR update + read-out, one launch per Euler step)",
+        "roofline": {"bound": "fabric", "bound_note": "the memory side of the contract's hbm | mfma choice; what limits the launch is the L2<->fabric "
+                     "random-row read rate, not HBM proper (`limiter`, DESIGN.md section 4.1)", "kernel": "k_step64<true> (software-pipelined CSR pull-gather + MFMA node MLPs + SIR update + read-out, one launch per Euler step)",
                      "achieved": gbs["compulsory"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs["compulsory"] / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_us": t_launch * 1e6, "launches": int(step_cnt),
@@ -342,6 +553,7 @@ def main():
                                 "working set cut to a quarter (4.8 MB per XCD) leaves 88 % of it (DESIGN.md section 4.1)"},
     }
 
+    result["rank_elapsed_s"] = {"min": min(rank_elapsed), "max": max(rank_elapsed), "per_rank": rank_elapsed}
     single = rank == 0 and world == 1
     sir_ctx = None
     if single and not args.no_secondary:
@@ -350,6 +562,9 @@ def main():
         try:
             result["train"] = {"configs[1] shape": bench_train(lib, dev, 1893, 13835, 8, 64, 30, 0.5, 10),
                                "75k graph x 4": bench_train(lib, dev, 75000, 500000, 4, 64, 30, 0.5, 3)}
+            result["train"]["configs[1] shape"]["gradient_vs_reference_classes"] = reference_fixture_gradient(dev)
+            result["mid"] = bench_mid(lib, dev)
+            result["h8"] = bench_h8(lib, dev)
             result["sir"], sir_ctx = bench_sir(lib, dev, 7066, 100736, 10000, 20)
         except Exception as exc:                                   # never lose the headline line to a secondary leg
             result["secondary_error"] = f"{type(exc).__name__}: {exc}"

@@ -1320,6 +1320,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
             const float *HubP0 = nullptr, *HubP1 = nullptr;        // segment partials; the interval kernel adds them up itself
             if (int e = gn_hub_segments2(g, rows / g->n, H, ZIb[cur], Qb[cur], hub_scratch, &HubP0, &HubP1, st)) return e;
             const int s = slot_of(i - 1);
+            const bool sampled = gn_prof_begin(2, st);
             BWD_DISPATCH(lpr, hipLaunchKernelGGL(k_bwd_fused_generic<LPR>, dim3(grid), dim3(256), fl * sizeof(float), st, g->rowptr,
                                                  g->col, g->n, (long)rows, H, ZS, ZIb[cur], Qb[cur], ZIb[cur ^ 1], Qb[cur ^ 1],
                                                  sol + (size_t)i * 4 * slab, sol + (size_t)(i - 1) * 4 * slab,
@@ -1328,6 +1329,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                                                  s >= 0 ? gI + (size_t)s * rows : nullptr, s >= 0 ? gR + (size_t)s * rows : nullptr,
                                                  p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias,
                                                  g->hubidx, HubP0, HubP1, g->hub_seg_ptr, g->n_seg, i > 1 ? 1 : 0));
+            if (sampled) gn_prof_end(2, st);
             GN_LAUNCH_CHECK();
         }
     } else
