@@ -372,31 +372,55 @@ def bwd_interval_bytes(n, nnz, H):
     return {"algorithmic": csr + nnz * H * 4 + slabs * slab, "compulsory": csr + slabs * slab}
 
 
+VALU_ISSUE_PEAK = 256 * 4 * 0.5 * 2.4e9      # wave-instructions / s: 1024 SIMDs, one wave64 vector instruction per 2 cycles (MI355X_MICROARCH.md)
+
+
 def bench_sir(lib, dev, n, m, sims, T):
+    """The Monte-Carlo label generator on configs[2]'s shape, two (beta, gamma) points: the bench's historical one (a fast
+    burn-through: everybody is infected within a few steps, most steps only draw recovery coins) and a long-lived frontier.
+    Work is COUNTED by the kernel's profiling instantiation (coins drawn, CSR entries read), not modelled."""
     import torch
     from gnode import synth
     from gnode.graph import DeviceGraph
-    from gnode.ode_nn import sir_counts
+    from gnode.ode_nn import sir_counts, sir_counts_counted
     rp, ci = synth.er_csr(n, m, seed=0)
     nnz = int(ci.shape[0])
     g = DeviceGraph(rp, ci)
-    seeds, beta, gamma = [1, n // 2], 0.3, 0.2
-    sir_counts(g, seeds, beta, gamma, 64, T, rng_seed=1)
-    torch.cuda.synchronize()
-    lib.gnode_profile_enable(1)
-    t0 = time.perf_counter()
-    cnt = sir_counts(g, seeds, beta, gamma, sims, T, rng_seed=2)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    k_ms, k_n = prof_read(lib, 3)
-    lib.gnode_profile_enable(0)
-    # events the kernel had to process: every (trajectory, step) walks the out-edges of the nodes infected at that step
-    inf = cnt[1, :T - 1].to(torch.float64).sum(1)                       # infected (trajectory, node) pairs per step
-    frontier_edges = float(inf.sum().item()) * nnz / n                  # expected out-edges of the frontier (ER: mean degree)
-    return {"shape": f"ER n={n} nnz={nnz}, {sims} sims x T={T}, 2 seeds, beta={beta}, gamma={gamma}", "seconds": dt,
-            "trajectory_steps_per_s": sims * (T - 1) / dt, "edge_visits_per_s_full_scan_equivalent": sims * (T - 1) * nnz / dt,
-            "frontier_edge_visits_per_s": frontier_edges / dt, "kernel_ms": k_ms if k_n else None,
-            "final_attack_rate": float(1.0 - cnt[0, T - 1].double().mean().item() / sims)}, (g, rp, ci, seeds, beta, gamma)
+    seeds = [1, n // 2]
+    out = {"shape": f"ER n={n} nnz={nnz}, {sims} sims x T={T}, 2 seeds"}
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_sir_latest.json")))
+    except Exception:
+        pass
+    for tag, beta, gamma in (("beta=0.3 gamma=0.2", 0.3, 0.2), ("beta=0.05 gamma=0.1", 0.05, 0.1)):
+        sir_counts(g, seeds, beta, gamma, 64, T, rng_seed=1)
+        torch.cuda.synchronize()
+        lib.gnode_profile_enable(1)
+        t0 = time.perf_counter()
+        cnt = sir_counts(g, seeds, beta, gamma, sims, T, rng_seed=2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        k_ms, k_n = prof_read(lib, 3)
+        lib.gnode_profile_enable(0)
+        cnt2, st = sir_counts_counted(g, seeds, beta, gamma, sims, T, rng_seed=2)
+        tk = (k_ms * 1e-3) if k_n else dt
+        rec = {"seconds": dt, "kernel_ms": k_ms if k_n else None, "trajectory_steps_per_s": sims * (T - 1) / dt,
+               "counted": st, "counted_run_same_counts": bool(torch.equal(cnt, cnt2)),
+               "coins_per_s": (st["infection_coins"] + st["recovery_coins"]) / tk, "csr_entries_per_s": st["csr_entries_read"] / tk,
+               "csr_bytes_per_s": 4.0 * st["csr_entries_read"] / tk,
+               "philox_int32_mul_frac_of_chip_rate": st["philox_blocks"] * 40 / tk / (VALU_ISSUE_PEAK * 64 / 4),
+               "final_attack_rate": float(1.0 - cnt[0, T - 1].double().mean().item() / sims)}
+        p = pmc.get(tag)
+        if p:
+            rec["valu_issue_frac_of_chip_rate"] = p["SQ_INSTS_VALU"] / tk / VALU_ISSUE_PEAK
+            rec["wave_cycle_shares"] = p.get("wave_cycle_shares")
+            rec["pmc_source"] = {"file": "profiles/pmc_sir_latest.json", "measured_in_this_run": False, "tree": pmc.get("tree")}
+        out[tag] = rec
+    out["limiter"] = ("latency, then vector issue: half of the waves' lifetime is s_waitcnt / barrier (dependent list -> row extent -> "
+                      "column ids -> bitmap loads, LDS atomics, 5 barriers per step), the vector units issue at ~1/3 of their rate; the "
+                      "Philox multiplies themselves are a few per cent of the chip's integer rate (DESIGN.md section 4.3)")
+    return out, (g, rp, ci, seeds, 0.3, 0.2)
 
 
 def main():

@@ -95,7 +95,9 @@ template <bool PRJ> struct StepOcc { static constexpr int value = PRJ ? GN_STEP_
 // reference's fb-social / wiki-vote experiments at batch size 1..8).  Nothing overlaps there but a tile's own round trips,
 // and the register file is nearly empty (one or two workgroups per CU), so the gather keeps 16 neighbour rows in flight
 // per lane group instead of 8: one dependent round trip less per tile.  Same sums in the same order: bit-identical outputs.
-template <bool PRJ, bool LAT = false>
+// HUBS: the graph has rows longer than the hub threshold (compile-time, so that graphs without them -- the benchmark's -- carry
+// neither the hub fields of the three in-flight stages nor their code: the 4-VGPR in-loop spill of round 2 is gone)
+template <bool PRJ, bool LAT = false, bool HUBS = true>
 __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(const int* __restrict__ rowhdr, const int* __restrict__ col, int n,
                                                  long rows, int tiles_per_sample, long total_tiles,
                                                  float* Y, const float* __restrict__ ZI,
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
             const int* h = rowhdr + (size_t)nodec * 20;
             s.start = h[0]; s.end = h[1];
             c0 = h[4 + sub];
-            if (hubidx) {                                  // uniform: graphs without long rows skip all of this
+            if (HUBS) {                                    // compile-time: graphs without long rows carry none of this
                 const int h = hubidx[nodec];
                 s.hub = s.valid && h >= 0;
                 // a hub row's neighbour sum arrives as per-segment partials (k_hub_seg): [hoff, hoff + hcnt rows) of HubP
@@ -227,8 +229,11 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
             const int cnt = cur.hub ? 0 : cur.end - cur.start;
             const unsigned m = cur.mine, m2 = cur.mine2;
 #define GP_R(V, K) GP_ACC(V) V = gat_ld<K>(ZI, (K) < 16 ? mm : mm2, lane_b); GP_SB
-#define GP_RA(K) GP_R(v0, K) GP_R(v1, (K) + 1) GP_R(v2, (K) + 2) GP_R(v3, (K) + 3)
-#define GP_RB(K) GP_R(v4, K) GP_R(v5, (K) + 1) GP_R(v6, (K) + 2) GP_R(v7, (K) + 3)
+            // (GP_RQ: the offsets are re-opaqued per group of four -- otherwise a long case computes all of its broadcast
+            //  addresses up front, and the longest one spilled a state register around its first loads)
+#define GP_RQ asm volatile("" : "+v"(mm), "+v"(mm2));
+#define GP_RA(K) GP_RQ GP_R(v0, K) GP_R(v1, (K) + 1) GP_R(v2, (K) + 2) GP_R(v3, (K) + 3)
+#define GP_RB(K) GP_RQ GP_R(v4, K) GP_R(v5, (K) + 1) GP_R(v6, (K) + 2) GP_R(v7, (K) + 3)
 #define GP_FA GP_ACC(v0) GP_ACC(v1) GP_ACC(v2) GP_ACC(v3) GP_ACC(v4) GP_ACC(v5) GP_ACC(v6) GP_ACC(v7)
 #define GP_FB GP_ACC(v4) GP_ACC(v5) GP_ACC(v6) GP_ACC(v7) GP_ACC(v0) GP_ACC(v1) GP_ACC(v2) GP_ACC(v3)
             // one straight-line path per gather length (wave-uniform switch): only `acc` is live at the join, so the eight
@@ -269,6 +274,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
 #undef GP_FA
 #undef GP_RB
 #undef GP_RA
+#undef GP_RQ
 #undef GP_R
             // rows of 33 .. hub-threshold edges: the plain chunked walk for the rest
             if (__any(cnt > 32)) {
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : StepOcc<PRJ>::value) void k_step64(c
                 v8 = gat_ld<8>(ZI, m, lane_b); v9 = gat_ld<9>(ZI, m, lane_b); v10 = gat_ld<10>(ZI, m, lane_b); v11 = gat_ld<11>(ZI, m, lane_b);
                 v12 = gat_ld<12>(ZI, m, lane_b); v13 = gat_ld<13>(ZI, m, lane_b); v14 = gat_ld<14>(ZI, m, lane_b); v15 = gat_ld<15>(ZI, m, lane_b);
             }
-            if (hubidx) {                                              // uniform: the graph has hub rows
+            if (HUBS) {                                                // compile-time: the graph has hub rows
                 // a hub row's sum = its segment partials added in segment order (what a separate reduction launch used to
                 // do: at mid size a launch costs as much as the step): 8 partial rows in flight, waves without a hub row skip
                 const int hc = n1.hcnt;
@@ -700,12 +706,14 @@ int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, flo
     // every slot and accepting a +-1 tile imbalance)
     const int grid = (int)std::min<long>(total, (long)g->num_cu * (PR ? StepOcc<true>::value : StepOcc<false>::value));
     const bool lat = total <= grid;            // one tile per workgroup: the latency-mode instantiation
-#define GN_STEP(P, L) hipLaunchKernelGGL((k_step64<P, L>), dim3(grid), dim3(256), 0, st, g->rowhdr, g->col, g->n, rows, tps, total, Y, ZI, \
+#define GN_STEP1(P, L, HB) hipLaunchKernelGGL((k_step64<P, L, HB>), dim3(grid), dim3(256), 0, st, g->rowhdr, g->col, g->n, rows, tps, total, Y, ZI, \
                                          ZI_next, W, bias, beta, gamma, dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight,     \
                                          p->linearS2_bias, PR, out, g->hubidx, HubP, g->hub_seg_ptr, g->n_seg)
-    if (PR) { if (lat) GN_STEP(true, true); else GN_STEP(true, false); }
-    else { if (lat) GN_STEP(false, true); else GN_STEP(false, false); }
+#define GN_STEP(P, L) { if (g->n_hub > 0) GN_STEP1(P, L, true); else GN_STEP1(P, L, false); }
+    if (PR) { if (lat) GN_STEP(true, true) else GN_STEP(true, false) }
+    else { if (lat) GN_STEP(false, true) else GN_STEP(false, false) }
 #undef GN_STEP
+#undef GN_STEP1
     GN_LAUNCH_CHECK();
     return 0;
 }

@@ -24,8 +24,10 @@
 enum : uint8_t { ST_S = 0, ST_I = 1, ST_R = 2 };
 
 // --------------------------------------------------------------------------- Philox4x32-10
-__device__ __forceinline__ uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                                 uint32_t k1) {
+// FOUR consecutive items (CSR positions for infection coins, node ids for recovery coins) share one block: the coin of item
+// pos is word (pos & 3) of philox(ctr = (pos >> 2, step, trajectory, kind), key).  Round 2 drew one block per coin and kept
+// one word of four: 40 quarter-rate 32-bit multiplies per coin, the kernel's main cost (oracle: philox_coin).
+__device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
@@ -33,7 +35,13 @@ __device__ __forceinline__ uint32_t philox_word0(uint32_t c0, uint32_t c1, uint3
         c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return c0;
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ __forceinline__ uint32_t philox_coin(uint32_t pos, uint32_t it, uint32_t sim, uint32_t kind, uint32_t k0, uint32_t k1) {
+    uint32_t w[4];
+    philox_block(pos >> 2, it, sim, kind, k0, k1, w);
+    const uint32_t j = pos & 3u;
+    return j == 0 ? w[0] : j == 1 ? w[1] : j == 2 ? w[2] : w[3];
 }
 
 // --------------------------------------------------------------------------- production kernel
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(1024) void k_sir_philox(const int* __restrict__ src
                 if (ON) {                                                                                     \
                     const int v = dst[E];                                                                     \
                     if (state[v] == ST_S &&                                                                   \
-                        (unsigned long long)philox_word0((uint32_t)(E), (uint32_t)it, sim, 0u, k0, k1) < thr_beta) \
+                        (unsigned long long)philox_coin((uint32_t)(E), (uint32_t)it, sim, 0u, k0, k1) < thr_beta) \
                         flag[v] = 1;                                                                          \
                 }
             long e = threadIdx.x;
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(1024) void k_sir_philox(const int* __restrict__ src
 #undef GN_EDGE
             for (int u = threadIdx.x; u < n; u += nthr)
                 if (state[u] == ST_I &&
-                    (unsigned long long)philox_word0((uint32_t)u, (uint32_t)it, sim, 1u, k0, k1) < thr_gamma)
+                    (unsigned long long)philox_coin((uint32_t)u, (uint32_t)it, sim, 1u, k0, k1) < thr_gamma)
                     flag[u] = 2;
             __syncthreads();
             int any = 0;
@@ -120,19 +128,25 @@ __global__ __launch_bounds__(1024) void k_sir_philox(const int* __restrict__ src
 #ifndef GN_SIR_BIGROW
 #define GN_SIR_BIGROW 512     // rows longer than this are walked by the whole workgroup
 #endif
-template <typename IdT, bool LISTS_IN_LDS>
+// COUNT: the profiling instantiation (gnode_sir_mc_philox_counted) also tallies Philox blocks, coins and CSR entries read.
+template <typename IdT, bool LISTS_IN_LDS, bool COUNT>
 __global__ __launch_bounds__(1024) void k_sir_frontier(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                       const int* __restrict__ seeds, int n_seeds,
                                                       unsigned long long thr_beta, unsigned long long thr_gamma,
                                                       long sims, long sim_offset, int T, uint32_t k0, uint32_t k1,
-                                                      uint32_t* __restrict__ hist, int32_t* __restrict__ glists) {
+                                                      uint32_t* __restrict__ hist, int32_t* __restrict__ glists,
+                                                      unsigned long long* __restrict__ stats) {
     extern __shared__ uint32_t smem_w[];
     const int nwords = (n + 31) >> 5;
     const int nw4 = (nwords + 3) & ~3;
     uint32_t* bits = smem_w;                                   // ever infected (seeds included): susceptible <=> bit clear
     uint32_t* spent = smem_w + nw4;                            // node whose neighbours have ALL been infected: its row can never
                                                                // infect anybody again (infection is monotone) and is not walked any more
-    IdT* lists = LISTS_IN_LDS ? reinterpret_cast<IdT*>(smem_w + 2 * nw4)
+    uint32_t* recb = smem_w + 2 * nw4;                         // recovered
+    // per-wave queue of (CSR position, target) pairs whose target was susceptible: their coins are drawn 64 at a time (below)
+    int* const cq = reinterpret_cast<int*>(smem_w + 3 * nw4) + (threadIdx.x >> 6) * 256;       // 128 positions | 128 targets
+    uint32_t* const after_q = smem_w + 3 * nw4 + (blockDim.x >> 6) * 256;
+    IdT* lists = LISTS_IN_LDS ? reinterpret_cast<IdT*>(after_q)
                               : reinterpret_cast<IdT*>(glists + (size_t)blockIdx.x * 3 * n);
     IdT* cur = lists;
     IdT* nxt = lists + n;
@@ -142,9 +156,10 @@ __global__ __launch_bounds__(1024) void k_sir_frontier(const int* __restrict__ r
     uint32_t* hrec = hist + (size_t)T * n;
     const int nthr = blockDim.x, tid = threadIdx.x;
     const int sub = tid & 15, gid = tid >> 4, ngroups = nthr >> 4, lane_in_wave = tid & 63;
+    unsigned long long st_blocks = 0, st_ecoins = 0, st_rcoins = 0, st_entries = 0;
     for (long s = blockIdx.x; s < sims; s += gridDim.x) {
         const uint32_t sim = (uint32_t)(sim_offset + s);
-        for (int w = tid; w < nwords; w += nthr) { bits[w] = 0u; spent[w] = 0u; }
+        for (int w = tid; w < nwords; w += nthr) { bits[w] = 0u; spent[w] = 0u; recb[w] = 0u; }
         if (tid < 3) cnt[tid] = 0;
         __syncthreads();
         for (int j = tid; j < n_seeds; j += nthr) {            // distinct seeds: one infection event at t = 0 each
@@ -160,48 +175,148 @@ __global__ __launch_bounds__(1024) void k_sir_frontier(const int* __restrict__ r
         for (int it = 1; it < T && n_inf > 0; ++it) {
             if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
             __syncthreads();
-            // infection attempts along the out-edges of the frontier: one 16-lane group per infected node
-            auto try_edge = [&](int e) -> bool {               // returns whether the edge's target was still susceptible
-                const int v = col[e];
-                const uint32_t m = 1u << (v & 31);
-                const bool sus = !(bits[v >> 5] & m);
-                if (sus &&
-                    (unsigned long long)philox_word0((uint32_t)e, (uint32_t)it, sim, 0u, k0, k1) < thr_beta) {
-                    if (!(atomicOr(&bits[v >> 5], m) & m)) {   // first edge to reach v this step (it was susceptible)
-                        nxt[atomicAdd(&cnt[0], 1)] = (IdT)v;
-                        atomicAdd(&cnt[2], 1);
-                        atomicAdd(&hinf[(size_t)it * n + v], 1u);
-                    }
+#ifndef GN_SIR_MODEB
+#define GN_SIR_MODEB 1
+#endif
+            if (GN_SIR_MODEB && n_ever >= n) {
+                // ---- everybody has been infected: only recovery coins remain, and the infected set is "not recovered".  No
+                // lists: a thread takes four consecutive nodes = ONE Philox block
+                int alive = 0;
+                for (int q = tid; 4 * q < n; q += nthr) {
+                    const int u0 = 4 * q;
+                    uint32_t nib = (~recb[u0 >> 5] >> (u0 & 31)) & 0xFu;
+                    if (u0 + 4 > n) nib &= (1u << (n - u0)) - 1u;
+                    if (!nib) continue;
+                    uint32_t w[4];
+                    philox_block((uint32_t)q, (uint32_t)it, sim, 1u, k0, k1, w);
+                    if (COUNT) { ++st_blocks; st_rcoins += __popc(nib); }
+                    uint32_t gone = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((nib >> j) & 1u) {
+                            if ((unsigned long long)w[j] < thr_gamma) { gone |= 1u << j; atomicAdd(&hrec[(size_t)it * n + u0 + j], 1u); }
+                            else ++alive;
+                        }
+                    if (gone) atomicOr(&recb[u0 >> 5], gone << (u0 & 31));
                 }
+                if (alive) atomicAdd(&cnt[0], alive);
+                __syncthreads();
+                n_inf = cnt[0];
+                __syncthreads();
+                continue;
+            }
+            // infection attempts along the out-edges of the frontier: one 16-lane group per infected node, a lane takes
+            // FOUR consecutive CSR positions (an aligned quad: one 16-byte read of the column list, one Philox block)
+            auto infect = [&](int v) {
+                const uint32_t m = 1u << (v & 31);
+                if (!(atomicOr(&bits[v >> 5], m) & m)) {       // first edge to reach v this step (it was susceptible)
+                    nxt[atomicAdd(&cnt[0], 1)] = (IdT)v;
+                    atomicAdd(&cnt[2], 1);
+                    atomicAdd(&hinf[(size_t)it * n + v], 1u);
+                }
+            };
+            // Counted on the wiki-vote-size workload (beta 0.3): 2.6e9 CSR entries read, 0.24e9 of them with a susceptible target.
+            // A coin drawn where it is found runs the ~60-instruction Philox sequence for the WHOLE wave whenever any of its 64
+            // lanes needs one -- almost always, at 9 % of the lanes: the kernel issued 4.7e9 vector instructions, two per CSR
+            // entry, ~40 % of the chip's issue rate, nearly all of it Philox on idle lanes.  So susceptible (position, target)
+            // pairs go through a per-wave LDS queue and their coins are drawn 64 at a time.  A target may now be queued by
+            // several rows before the first coin infects it; the extra coins change nothing (infection = OR over the coins of
+            // the edges whose target was susceptible at the start of the step, exactly the reference's rule).
+            int qn = 0;                                        // wave-uniform queue length
+            auto drain = [&](int take) {                       // the last `take` (<= 64) queued pairs
+                const int slot = qn - take + lane_in_wave;
+                if (lane_in_wave < take) {
+                    const int e = cq[slot], v = cq[128 + slot];
+                    if (COUNT) { ++st_blocks; ++st_ecoins; }
+                    if ((unsigned long long)philox_coin((uint32_t)e, (uint32_t)it, sim, 0u, k0, k1) < thr_beta) infect(v);
+                }
+                qn -= take;
+            };
+            auto push = [&](bool sus, int e, int v) {          // every lane of the wave calls it (sus = false: nothing to add)
+                const unsigned long long mk = __ballot(sus);
+                if (sus) { const int slot = qn + __popcll(mk & ((1ull << lane_in_wave) - 1ull)); cq[slot] = e; cq[128 + slot] = v; }
+                qn += __popcll(mk);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= 64) drain(64);
+            };
+            auto try_edge = [&](int e, bool on) -> bool {      // one lane per CSR position; `on`: this lane has an entry
+                const int v = on ? col[e] : 0;
+                const bool sus = on && !(bits[v >> 5] & (1u << (v & 31)));
+                if (COUNT && on) ++st_entries;
+                push(sus, e, v);
                 return sus;
             };
-            if (n_ever < n)
-            for (int idx = gid; idx < n_inf; idx += ngroups) {
-                const int u = (int)cur[idx];
-                const uint32_t um = 1u << (u & 31);
-                if (spent[u >> 5] & um) continue;              // every neighbour already infected: nothing left to do for u
-                const int lo = rowptr[u], hi = rowptr[u + 1];
-                if (hi - lo > GN_SIR_BIGROW) { if (sub == 0) big[atomicAdd(&cnt[1], 1)] = (IdT)u; continue; }
-                bool any_sus = false;
-                for (int e = lo + sub; e < hi; e += 16) any_sus |= try_edge(e);
-                // (a target infected during this very walk still counted as susceptible: the row is retired one step later)
-                const unsigned long long bal = __ballot(any_sus);
-                if (sub == 0 && !((bal >> (lane_in_wave & 48)) & 0xFFFFull)) atomicOr(&spent[u >> 5], um);
+            // The walk of one frontier row is a chain of dependent loads (list entry -> row extent -> column ids -> bitmap), ~2 us
+            // of L2 round trips for a few dozen integer instructions: counted, the wiki-vote-size workload reads 2.8e9 CSR
+            // entries and draws 0.58e9 coins in 10 ms, an order of magnitude below both the integer and the L2 rate --
+            // it was LATENCY bound, one row per lane group at a time.  So the rows are software-pipelined three deep per lane
+            // group: while row i is tested, the column ids of row i+1 and the extent of row i+2 are in flight.
+            struct Row { int u, lo, hi, ca, cb; };
+            Row r1 = {-1, 0, 0, 0, 0}, r2 = {-1, 0, 0, 0, 0};
+            for (int idx = gid; __any(idx < n_inf + 2 * ngroups); idx += ngroups) {
+                // stage A: the next row's node and extent
+                Row r0 = {-1, 0, 0, 0, 0};
+                if (idx < n_inf) {
+                    const int u = (int)cur[idx];
+                    if (!(spent[u >> 5] & (1u << (u & 31)))) { r0.u = u; r0.lo = rowptr[u]; r0.hi = rowptr[u + 1]; }   // (spent: nothing left to do for u)
+                }
+                // stage B: column ids 0..31 of the row fetched one iteration ago (rows for the whole workgroup go on `big`)
+                if (r1.u >= 0) {
+                    if (r1.hi - r1.lo > GN_SIR_BIGROW) { if (sub == 0) big[atomicAdd(&cnt[1], 1)] = (IdT)r1.u; r1.u = -1; }
+                    else {
+                        if (r1.lo + sub < r1.hi) r1.ca = col[r1.lo + sub];
+                        if (r1.lo + 16 + sub < r1.hi) r1.cb = col[r1.lo + 16 + sub];
+                    }
+                }
+                // stage C: test the row whose column ids were requested one iteration ago (wave-uniform control flow: the
+                // queue's ballots need every lane)
+                {
+                    bool any_sus = false;
+                    auto test = [&](bool on, int e, int v) {
+                        const bool sus = on && !(bits[v >> 5] & (1u << (v & 31)));
+                        if (COUNT && on) ++st_entries;
+                        push(sus, e, v);
+                        any_sus |= sus;
+                    };
+                    const bool live = r2.u >= 0;
+                    test(live && r2.lo + sub < r2.hi, r2.lo + sub, r2.ca);
+                    if (__any(live && r2.hi - r2.lo > 16)) test(live && r2.lo + 16 + sub < r2.hi, r2.lo + 16 + sub, r2.cb);
+                    for (int e0 = 32; __any(live && r2.lo + e0 < r2.hi); e0 += 16) {
+                        const int e = r2.lo + e0 + sub;
+                        const bool on = live && e < r2.hi;
+                        test(on, e, on ? col[e] : 0);
+                    }
+                    // (a target infected during this very walk still counted as susceptible: the row is retired one step later)
+                    const unsigned long long bal = __ballot(any_sus);
+                    if (live && sub == 0 && !((bal >> (lane_in_wave & 48)) & 0xFFFFull)) atomicOr(&spent[r2.u >> 5], 1u << (r2.u & 31));
+                }
+                r2 = r1; r1 = r0;
             }
+            if (qn > 0) drain(qn);
             // recovery coin of every node of the frontier (decided on the pre-step state: a node infected in this step is
             // not on `cur`); survivors go on the next list
             for (int idx = tid; idx < n_inf; idx += nthr) {
                 const int u = (int)cur[idx];
-                if ((unsigned long long)philox_word0((uint32_t)u, (uint32_t)it, sim, 1u, k0, k1) < thr_gamma)
+                if (COUNT) { ++st_blocks; ++st_rcoins; }
+                const bool gone = (unsigned long long)philox_coin((uint32_t)u, (uint32_t)it, sim, 1u, k0, k1) < thr_gamma;
+                if (gone) {
                     atomicAdd(&hrec[(size_t)it * n + u], 1u);
-                else
-                    nxt[atomicAdd(&cnt[0], 1)] = (IdT)u;
+                    atomicOr(&recb[u >> 5], 1u << (u & 31));
+                }
+                // survivors go on the next list: ONE LDS atomic per wave (64 lanes adding to the same word serialise)
+                const unsigned long long keep = __ballot(!gone);
+                int basep = 0;
+                if (lane_in_wave == 0 && keep) basep = atomicAdd(&cnt[0], __popcll(keep));
+                basep = __shfl(basep, 0, 64);
+                if (!gone) nxt[basep + __popcll(keep & ((1ull << lane_in_wave) - 1ull))] = (IdT)u;
             }
             __syncthreads();
             const int n_big = cnt[1];
             for (int b = 0; b < n_big; ++b) {                   // hub rows: the whole workgroup strides one row
                 const int u = (int)big[b];
-                for (int e = rowptr[u] + tid; e < rowptr[u + 1]; e += nthr) try_edge(e);
+                const int lo = rowptr[u], hi = rowptr[u + 1];
+                for (int e0 = lo; e0 < hi; e0 += nthr) try_edge(e0 + tid, e0 + tid < hi);
+                if (qn > 0) drain(qn);
             }
             __syncthreads();
             n_inf = cnt[0];
@@ -209,6 +324,9 @@ __global__ __launch_bounds__(1024) void k_sir_frontier(const int* __restrict__ r
             IdT* t = cur; cur = nxt; nxt = t;
             __syncthreads();
         }
+    }
+    if (COUNT) {
+        atomicAdd(&stats[0], st_blocks); atomicAdd(&stats[1], st_ecoins); atomicAdd(&stats[2], st_rcoins); atomicAdd(&stats[3], st_entries);
     }
 }
 
@@ -332,14 +450,24 @@ __global__ void k_put_seeds(SeedArg sa, int n_seeds, int32_t* __restrict__ seeds
 }
 
 // LDS of the frontier kernel: bitmap (+ three uint16 node lists -- current, next, long rows -- when they fit)
-static size_t frontier_bitmap_bytes(int n) { return 2 * ((((size_t)n + 31) / 32 + 3) & ~(size_t)3) * 4; }   // ever-infected + spent
+static size_t frontier_bitmap_bytes(int n) { return 3 * ((((size_t)n + 31) / 32 + 3) & ~(size_t)3) * 4; }   // ever-infected + spent + recovered
 static bool frontier_lists_in_lds(int n) { return n <= 65536 && frontier_bitmap_bytes(n) + 6 * (size_t)n <= 48 * 1024; }
-static size_t frontier_lds_bytes(int n) { return frontier_bitmap_bytes(n) + (frontier_lists_in_lds(n) ? 6 * (size_t)n : 0); }
+// + 1 KB of coin queue per wave
+static size_t frontier_lds_bytes(int n, int threads) { return frontier_bitmap_bytes(n) + (size_t)(threads / 64) * 1024 + (frontier_lists_in_lds(n) ? 6 * (size_t)n : 0); }
+// workgroup size: the smallest of 256 / 512 / 1024 threads that still puts >= 16 waves on a CU (the LDS decides how many fit)
+static int frontier_threads(int n, int* per_cu_out) {
+    for (int threads = 256; ; threads *= 2) {
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (frontier_lds_bytes(n, threads) + 64)));
+        if (per_cu * (threads / 64) >= 16 || threads == 1024) { *per_cu_out = per_cu; return threads; }
+    }
+}
 static const int kFrontierGlobalGrid = 1024;       // workgroups that own a set of global lists (graphs past the LDS form)
 
 int gn_sir_set_attributes() {       // once per device, from gnode_graph_create
-    GN_HIP(hipFuncSetAttribute((const void*)k_sir_frontier<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
-    GN_HIP(hipFuncSetAttribute((const void*)k_sir_frontier<int32_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
+    GN_HIP(hipFuncSetAttribute((const void*)k_sir_frontier<uint16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
+    GN_HIP(hipFuncSetAttribute((const void*)k_sir_frontier<int32_t, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
+    GN_HIP(hipFuncSetAttribute((const void*)k_sir_frontier<uint16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
+    GN_HIP(hipFuncSetAttribute((const void*)k_sir_frontier<int32_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
     GN_HIP(hipFuncSetAttribute((const void*)k_sir_philox<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
     GN_HIP(hipFuncSetAttribute((const void*)k_sir_coins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsStateLimit));
     return 0;
@@ -359,7 +487,8 @@ extern "C" size_t gnode_sir_workspace_bytes(gnode_graph_t g, int32_t T) {
 
 static int sir_mc_philox_impl(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta,
                               double gamma, int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed,
-                              uint32_t* counts, void* workspace, size_t workspace_bytes, void* stream, bool edge_scan) {
+                              uint32_t* counts, void* workspace, size_t workspace_bytes, void* stream, bool edge_scan,
+                              unsigned long long* stats = nullptr /* device [4]: the counting instantiation, or null */) {
     GN_CHECK_ARG(g && counts && workspace, "gnode_sir_mc_philox: null pointer");
     GN_CHECK_ARG(n_seeds >= 0 && n_seeds <= 4096 && (seeds_host || n_seeds == 0), "gnode_sir_mc_philox: 0..4096 seeds");
     GN_CHECK_ARG(T >= 1 && sims >= 0 && sims <= 0xFFFFFFFFll && sim_offset >= 0 && sim_offset + sims <= 0xFFFFFFFFll,
@@ -397,20 +526,25 @@ static int sir_mc_philox_impl(gnode_graph_t g, const int32_t* seeds_host, int32_
     const uint32_t k0 = (uint32_t)(rng_seed & 0xFFFFFFFFull), k1 = (uint32_t)(rng_seed >> 32);
     if (sims > 0) {
         const bool sampled = gn_prof_begin(3, st);
-        const size_t fl = frontier_lds_bytes(g->n);
+        int per_cu_f = 1;
+        const int threads_f = frontier_threads(g->n, &per_cu_f);
+        const size_t fl = frontier_lds_bytes(g->n, threads_f);
         const size_t lds = (size_t)2 * g->n;
         if (fl <= kLdsStateLimit && !edge_scan) {
             // frontier-driven walk.  Workgroups per CU by LDS, at least 16 waves per CU
-            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(fl + 64, 1)));
-            const int threads = per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024);
+            const int per_cu = per_cu_f, threads = threads_f;
             if (frontier_lists_in_lds(g->n)) {
                 const int grid = (int)std::min<int64_t>(sims, (int64_t)g->num_cu * per_cu);
-                hipLaunchKernelGGL((k_sir_frontier<uint16_t, true>), dim3(grid), dim3(threads), fl, st, g->rowptr, g->col, g->n, seeds,
-                                   n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (int32_t*)nullptr);
+                if (stats) hipLaunchKernelGGL((k_sir_frontier<uint16_t, true, true>), dim3(grid), dim3(threads), fl, st, g->rowptr, g->col, g->n, seeds,
+                                              n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (int32_t*)nullptr, stats);
+                else hipLaunchKernelGGL((k_sir_frontier<uint16_t, true, false>), dim3(grid), dim3(threads), fl, st, g->rowptr, g->col, g->n, seeds,
+                                        n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (int32_t*)nullptr, stats);
             } else {
                 const int grid = (int)std::min<int64_t>(std::min<int64_t>(sims, (int64_t)g->num_cu * per_cu), kFrontierGlobalGrid);
-                hipLaunchKernelGGL((k_sir_frontier<int32_t, false>), dim3(grid), dim3(threads), fl, st, g->rowptr, g->col, g->n, seeds,
-                                   n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (int32_t*)gstate);
+                if (stats) hipLaunchKernelGGL((k_sir_frontier<int32_t, false, true>), dim3(grid), dim3(threads), fl, st, g->rowptr, g->col, g->n, seeds,
+                                              n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (int32_t*)gstate, stats);
+                else hipLaunchKernelGGL((k_sir_frontier<int32_t, false, false>), dim3(grid), dim3(threads), fl, st, g->rowptr, g->col, g->n, seeds,
+                                        n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (int32_t*)gstate, stats);
             }
         } else if (lds <= kLdsStateLimit) {
             // edge-parallel scan, node state in LDS: graphs whose frontier lists do not fit (n > ~25k with 32-bit ids)
@@ -439,6 +573,27 @@ extern "C" int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, i
                                    uint32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
     return sir_mc_philox_impl(g, seeds_host, n_seeds, beta, gamma, sims, sim_offset, T, rng_seed, counts, workspace,
                               workspace_bytes, stream, false);
+}
+
+// The production kernel's profiling instantiation: the same counts, plus what the launch did -- stats_host[0] Philox blocks
+// computed, [1] infection coins drawn, [2] recovery coins drawn, [3] CSR entries read.  Synchronises `stream`.
+extern "C" int gnode_sir_mc_philox_counted(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta,
+                                           double gamma, int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed,
+                                           uint32_t* counts, void* workspace, size_t workspace_bytes, void* stream,
+                                           uint64_t* stats_host) {
+    GN_CHECK_ARG(stats_host && workspace, "gnode_sir_mc_philox_counted: null pointer");
+    GN_CHECK_ARG(workspace_bytes >= gnode_sir_workspace_bytes(g, T), "gnode_sir_mc_philox_counted: workspace too small");
+    // the tally lives in the (otherwise unused by the frontier walk) row-expansion region of the workspace
+    char* ws = (char*)workspace;
+    unsigned long long* stats = (unsigned long long*)(ws + gn_align((size_t)2 * T * g->n * sizeof(uint32_t)) + gn_align(4096 * sizeof(int32_t)));
+    GN_CHECK_ARG(g->nnz >= 8, "gnode_sir_mc_philox_counted: graph too small");
+    GN_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));
+    if (int e = sir_mc_philox_impl(g, seeds_host, n_seeds, beta, gamma, sims, sim_offset, T, rng_seed, counts, workspace,
+                                   workspace_bytes, stream, false, stats))
+        return e;
+    GN_HIP(hipMemcpyAsync(stats_host, stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GN_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
 }
 
 extern "C" int gnode_sir_mc_philox_scan(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta,

@@ -20,7 +20,7 @@ EXPORTS = [
     "gnode_forward_workspace_bytes", "gnode_forward_f32", "gnode_forward_status", "gnode_forward_path", "gnode_sol_carries_neighbour_sums", "gnode_forward_keep_bytes",
     "gnode_backward_workspace_bytes", "gnode_backward_f32",
     "gnode_sir_workspace_bytes", "gnode_sir_coins_workspace_bytes",
-    "gnode_sir_mc_philox", "gnode_sir_mc_philox_scan", "gnode_sir_mc_coins",
+    "gnode_sir_mc_philox", "gnode_sir_mc_philox_scan", "gnode_sir_mc_philox_counted", "gnode_sir_mc_coins",
     "gnode_dmp_workspace_bytes", "gnode_dmp_f32",
     "gnode_meanfield_workspace_bytes", "gnode_meanfield_f64",
     "gnode_l1_loss_workspace_bytes", "gnode_l1_loss_f32",
@@ -98,6 +98,8 @@ def load():
     lib.gnode_sir_mc_philox.argtypes = [vp, vp, i32, C.c_double, C.c_double, i64, i64, i32, C.c_uint64, vp, vp, sz, vp]
     lib.gnode_sir_mc_philox_scan.argtypes = lib.gnode_sir_mc_philox.argtypes
     lib.gnode_sir_mc_philox_scan.restype = C.c_int
+    lib.gnode_sir_mc_philox_counted.argtypes = lib.gnode_sir_mc_philox.argtypes + [C.POINTER(C.c_uint64)]
+    lib.gnode_sir_mc_philox_counted.restype = C.c_int
     lib.gnode_sir_mc_coins.argtypes = [vp, vp, i64, i32, vp, i32, C.c_double, C.c_double, i64, i32, vp, i64, vp,
                                        C.POINTER(i64), vp, sz, vp]
     lib.gnode_profile_enable.argtypes = [C.c_int]

@@ -75,6 +75,20 @@ def sir_counts(graph: DeviceGraph, seed_set, beta, gamma, sims, T, rng_seed, sim
     return counts
 
 
+def sir_counts_counted(graph: DeviceGraph, seed_set, beta, gamma, sims, T, rng_seed, sim_offset=0, device="cuda"):
+    """`sir_counts` through the kernel's profiling instantiation: (counts, stats) with stats = what the launch did --
+    Philox blocks computed, infection coins drawn, recovery coins drawn, CSR entries read (bench.py's `sir` roofline)."""
+    lib = _lib.load()
+    seeds = np.ascontiguousarray(list(seed_set), dtype=np.int32)
+    counts = torch.zeros((3, T, graph.n), dtype=torch.int32, device=device)
+    ws = torch.empty(lib.gnode_sir_workspace_bytes(graph.handle, T), dtype=torch.uint8, device=counts.device)
+    st = (C.c_uint64 * 4)()
+    _lib.check(lib.gnode_sir_mc_philox_counted(graph.handle, _lib.host_ptr(seeds), int(seeds.shape[0]), float(beta), float(gamma),
+                                               int(sims), int(sim_offset), int(T), C.c_uint64(int(rng_seed) & (2**64 - 1)),
+                                               _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), st))
+    return counts, {"philox_blocks": int(st[0]), "infection_coins": int(st[1]), "recovery_coins": int(st[2]), "csr_entries_read": int(st[3])}
+
+
 def sir_counts_coins(n, table: np.ndarray, seed_set, beta, gamma, sims, T, coins: np.ndarray, device="cuda"):
     """Parity mode: consume a recorded torch.rand stream exactly like the reference.
     Returns (counts int32 [3,T,n] on the GPU, coins consumed)."""

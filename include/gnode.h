@@ -195,8 +195,9 @@ int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_params* p, c
  *
  * gnode_sir_mc_philox: production mode.  One workgroup per trajectory walking the
  * out-edges of its current frontier (work per step = the frontier's out-degree, not
- * nnz); coins are counter-based Philox4x32-10 keyed by (CSR position|node, step,
- * sim, kind) so that neither the visiting order nor any sharding of
+ * nnz); coins are counter-based Philox4x32-10: the coin of CSR position / node id p is
+ * word (p & 3) of the block keyed (p >> 2, step, sim, kind) -- four consecutive items
+ * share one block, which a lane computes once -- so that neither the visiting order nor any sharding of
  * [sim_offset, sim_offset+sims) over GPUs can change a count.  counts: device uint32 [3, T, n] (S, I, R), ACCUMULATED into (caller
  * zeroes it); rows t >= 1 add one per trajectory per node, row 0 of S and I is
  * written with the initial state once (reference quirk: assigned, ode_nn.py:55-56).
@@ -223,6 +224,12 @@ int gnode_sir_mc_philox(gnode_graph_t g, const int32_t* seeds_host, int32_t n_se
 int gnode_sir_mc_philox_scan(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta, double gamma,
                              int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed, uint32_t* counts,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* gnode_sir_mc_philox through the kernel's PROFILING instantiation (a template flag, not a different algorithm): the same
+ * counts, plus what the launch did -- stats_host[0] Philox blocks computed, [1] infection coins drawn, [2] recovery coins
+ * drawn, [3] CSR entries read (bench.py prices the kernel against the chip's integer rate with them).  Synchronises `stream`. */
+int gnode_sir_mc_philox_counted(gnode_graph_t g, const int32_t* seeds_host, int32_t n_seeds, double beta, double gamma,
+                                int64_t sims, int64_t sim_offset, int32_t T, uint64_t rng_seed, uint32_t* counts,
+                                void* workspace, size_t workspace_bytes, void* stream, uint64_t* stats_host);
 int gnode_sir_mc_coins(const int32_t* table_src, const int32_t* table_dst, int64_t n_table, int32_t n,
                        const int32_t* seeds_host, int32_t n_seeds, double beta, double gamma, int64_t sims,
                        int32_t T, const double* coins, int64_t n_coins, uint32_t* counts,

@@ -130,7 +130,7 @@ void oracle_forward_euler(const int32_t* rowptr, const int32_t* col, int n, long
 }
 
 /* ---- Philox4x32-10 + production Monte-Carlo (spec: gnode_oracle.py sir_philox) ---- */
-static inline uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+static inline void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
@@ -138,7 +138,13 @@ static inline uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint3
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return c0;
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+/* the coin of item `pos` (CSR position, kind 0; node id, kind 1): four consecutive items share one block (gnode_oracle.py philox_coin) */
+static inline uint32_t philox_coin(uint32_t pos, uint32_t it, uint32_t sim, uint32_t kind, uint32_t k0, uint32_t k1) {
+    uint32_t w[4];
+    philox_block(pos >> 2, it, sim, kind, k0, k1, w);
+    return w[pos & 3u];
 }
 
 static uint64_t coin_threshold(double p) {
@@ -169,9 +175,9 @@ void oracle_sir_philox(const int32_t* rowptr, const int32_t* col, int n, const i
                     if (st[u] != 1) continue;
                     for (int e = rowptr[u]; e < rowptr[u + 1]; ++e) {
                         const int v = col[e];
-                        if (st[v] == 0 && (uint64_t)philox_word0((uint32_t)e, (uint32_t)it, sim, 0u, k0, k1) < tb) fl[v] = 1;
+                        if (st[v] == 0 && (uint64_t)philox_coin((uint32_t)e, (uint32_t)it, sim, 0u, k0, k1) < tb) fl[v] = 1;
                     }
-                    if ((uint64_t)philox_word0((uint32_t)u, (uint32_t)it, sim, 1u, k0, k1) < tg) fl[u] = 2;
+                    if ((uint64_t)philox_coin((uint32_t)u, (uint32_t)it, sim, 1u, k0, k1) < tg) fl[u] = 2;
                 }
                 for (int v = 0; v < n; ++v) {
                     if (fl[v] == 1) st[v] = 1; else if (fl[v] == 2) st[v] = 2;

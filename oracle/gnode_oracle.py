@@ -319,9 +319,8 @@ def sir_coins(n, table, seed_set, beta, gamma, sims, T, coins):
 M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Philox4x32-10 (Salmon et al. 2011), vectorised over numpy uint64 holders.
-    Returns word 0 of the output block as uint32 array."""
+def philox4x32_10_block(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al. 2011), vectorised over numpy uint64 holders: the four output words as uint32 arrays."""
     c0 = np.asarray(c0, dtype=np.uint64); c1 = np.asarray(c1, dtype=np.uint64)
     c2 = np.asarray(c2, dtype=np.uint64); c3 = np.asarray(c3, dtype=np.uint64)
     c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
@@ -335,7 +334,22 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
         c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & mask, lo1, (hi0 ^ c3 ^ k1) & mask, lo0
         k0 = (k0 + np.uint64(W0)) & mask
         k1 = (k1 + np.uint64(W1)) & mask
-    return c0.astype(np.uint32)
+    return tuple(np.asarray(c).astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Word 0 of the Philox4x32-10 output block as uint32 array."""
+    return philox4x32_10_block(c0, c1, c2, c3, k0, k1)[0]
+
+
+def philox_coin(pos, it, sim, kind, k0, k1):
+    """The coin of item `pos` (a CSR position for kind 0 = infection, a node id for kind 1 = recovery): FOUR consecutive
+    items share one Philox block -- word (pos & 3) of philox(ctr = (pos >> 2, it, sim, kind), key).  (One block per coin
+    spent all ten rounds on one word of four; the kernels' lanes walk four consecutive items per block instead.)"""
+    pos = np.asarray(pos, dtype=np.uint64)
+    w = philox4x32_10_block(pos >> np.uint64(2), it, sim, kind, k0, k1)
+    sel = (pos & np.uint64(3)).astype(np.int64)
+    return np.choose(sel, [np.broadcast_to(x, sel.shape) for x in w]).astype(np.uint64) if sel.size else np.zeros(0, dtype=np.uint64)
 
 
 def coin_threshold(p):
@@ -348,8 +362,8 @@ def sir_philox(n, rowptr, col, seed_set, beta, gamma, sims, T, rng_seed, sim_off
     with counter-based coins instead of torch's CPU stream.
 
     Infection coin of directed CSR edge e (row u -> col[e]) in sim s at step it:
-        philox(ctr=(e, it, s, 0), key=(seed_lo, seed_hi)) < thr(beta)
-    Recovery coin of node u:  philox(ctr=(u, it, s, 1), key) < thr(gamma).
+        word (e & 3) of philox(ctr=(e >> 2, it, s, 0), key=(seed_lo, seed_hi)) < thr(beta)
+    Recovery coin of node u:  word (u & 3) of philox(ctr=(u >> 2, it, s, 1), key) < thr(gamma)      (philox_coin).
     Both are decided on the pre-step state.  s = sim_offset + local index, so a
     sims-sharded run over several GPUs reproduces the single-GPU counts exactly.
     Returns uint32 counts [3, T, n] (S, I, R) with the reference's row-0 quirk
@@ -367,10 +381,10 @@ def sir_philox(n, rowptr, col, seed_set, beta, gamma, sims, T, rng_seed, sim_off
         cnt[0, 0] = S; cnt[1, 0] = I
         for it in range(1, T):
             act = np.nonzero(I[src] & S[dst])[0]
-            w = philox4x32_10(eid[act], it, s, 0, k0, k1).astype(np.uint64)
+            w = philox_coin(eid[act], it, s, 0, k0, k1)
             new_inf = dst[act[w < tb]]
             idx_I = np.nonzero(I)[0]
-            w2 = philox4x32_10(idx_I.astype(np.uint64), it, s, 1, k0, k1).astype(np.uint64)
+            w2 = philox_coin(idx_I.astype(np.uint64), it, s, 1, k0, k1)
             new_rec = idx_I[w2 < tg]
             R[new_rec] = True
             I[new_inf] = True; I[new_rec] = False; S[new_inf] = False

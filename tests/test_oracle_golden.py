@@ -113,6 +113,14 @@ def test_philox_known_answer():
     """Random123 known-answer vectors for philox4x32-10."""
     assert int(O.philox4x32_10(0, 0, 0, 0, 0, 0)) == 0x6627E8D5
     assert int(O.philox4x32_10(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)) == 0x408F276D
+    # whole blocks (the Monte-Carlo coins use all four words: four consecutive CSR positions / node ids per block)
+    blk = lambda *a: [int(w) for w in O.philox4x32_10_block(*a)]
+    assert blk(0, 0, 0, 0, 0, 0) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert blk(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert blk(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0) == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    # the coin of item pos = word (pos & 3) of block pos >> 2
+    w = O.philox4x32_10_block(5, 3, 7, 1, 11, 13)
+    assert [int(v) for v in O.philox_coin(np.asarray([20, 21, 22, 23]), 3, 7, 1, 11, 13)] == [int(x) for x in w]
     assert int(O.philox4x32_10(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0)) == 0xD16CFE09
 
 
