@@ -211,6 +211,57 @@ def reference_fixture_gradient(dev):
             "pass": bool(max(rel.values()) <= 2e-4)}
 
 
+def bench_train_dist(lib, dev, dist, world, rank, backend):
+    import scipy.sparse as sp
+    import torch
+    from gnode import ops, sharding, synth
+    from gnode.autograd import l1_loss_sum
+    from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
+    n, m, B, H, maxTime, deltaT = 1893, 13835, 8, 64, 30, 0.5
+    rp, ci = synth.er_csr(n, m, seed=0)
+    A = sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n))
+    model = ODEBlock(maxTime, deltaT, n, [0], H, ODEfunc(A, 0.2, 0.1, H, dev), dev).to(dev)
+    model.load_state_dict({**model.state_dict(), **{k: torch.from_numpy(v) for k, v in synth.linear_params(H, seed=0).items()}})
+    x = torch.from_numpy(synth.samples(n, B, H, seed=100 + rank)).to(dev)
+    y = torch.from_numpy(np.random.default_rng(rank).dirichlet(np.ones(3), size=(B * n, maxTime))).to(dev)
+    rows = ops.subsample_rows(maxTime, deltaT)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    params = list(model.parameters())
+    scale = 1.0 / (world * B * n * (maxTime - 1) * 3)            # element mean over the GLOBAL batch (ode_nn_ngraph_sim.py:248-249)
+    t_ar = [0.0]
+
+    def step(time_ar):
+        opt.zero_grad()
+        S, I, R = model(x, out_rows=rows)
+        l1_loss_sum(S, I, R, y, 1).backward()
+        if time_ar:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        sharding.allreduce_flat_grads(params, scale=scale)
+        if time_ar:
+            torch.cuda.synchronize(); t_ar[0] += time.perf_counter() - t0
+        opt.step()
+
+    for _ in range(3):
+        step(False)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        step(False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for _ in range(reps):
+        step(True)
+    t = torch.tensor([dt / reps, t_ar[0] / reps], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    w0 = params[0].detach().double().sum().reshape(1).to(t.device)
+    wmin, wmax = w0.clone(), w0.clone()
+    dist.all_reduce(wmin, op=dist.ReduceOp.MIN); dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
+    return {"shape": f"ER n={n}, {B} samples per rank x {world} ranks, H={H}, 59 Euler steps", "ms_per_step_max_over_ranks": float(t[0]) * 1e3,
+            "gradient_allreduce_ms (4 809 floats, flat, timed with a sync on both sides)": float(t[1]) * 1e3,
+            "samples_per_s": world * B / float(t[0]), "weights_identical_on_all_ranks": bool(float(wmin) == float(wmax))}
+
+
 def _ev_ms(fn, reps, warm=2):
     import torch
     for _ in range(warm):
@@ -468,9 +519,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from gnode import _lib, ops, synth
+    from gnode import _lib, ops, sharding, synth
     from gnode.graph import DeviceGraph
 
+    if world > max(torch.cuda.device_count(), 1):
+        sharding.share_device_guard()            # rehearsal with several ranks on one GPU: no persistent launches (see there)
     lib = _lib.load()
     n, H, B = args.nodes, args.hidden, args.samples
     rp, ci = synth.er_csr(n, args.edges, seed=0)
@@ -578,6 +631,13 @@ def main():
     }
 
     result["rank_elapsed_s"] = {"min": min(rank_elapsed), "max": max(rank_elapsed), "per_rank": rank_elapsed}
+    if world > 1 and not args.no_secondary:
+        # data-parallel training step on configs[1]'s shape, 8 samples per rank: local forward + adjoint backward, ONE flat
+        # all-reduce of the 4 809-float gradient, identical Adam step on every rank; the all-reduce is timed on its own
+        try:
+            result["train_dist"] = bench_train_dist(lib, dev, dist, world, rank, backend)
+        except Exception as exc:
+            result["train_dist"] = f"unavailable: {type(exc).__name__}: {exc}"
     single = rank == 0 and world == 1
     sir_ctx = None
     if single and not args.no_secondary:

@@ -1269,7 +1269,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
             const int cur = (G - 1 - i) & 1;
             const bool two = !ai_saved || i == G - 1;          // A Z_I(y_{G-1}) was never needed by the forward
             const float *AIhub = nullptr, *GQhub = nullptr;
-            const bool kept_launch = keep && !two && rows < (1L << 24);
+            const bool kept_launch = keep && !two && rows < (1L << 24) && (long)(rows / g->n) * g->n_seg < (1L << 24);   // 32-bit byte offsets of rows and hub partials
             const float* HubP = nullptr;               // kept kernel: segment partials only, it adds them up itself
             if (two) { if (int e = gn_hub_gather(g, rows / g->n, 64, ZIb[cur], Qb[cur], hub_scratch, &AIhub, &GQhub, st)) return e; }
             else if (kept_launch) { if (int e = gn_hub_segments(g, rows / g->n, 64, Qb[cur], hub_scratch, &HubP, st)) return e; }

@@ -697,6 +697,9 @@ int gn_launch_step64(gnode_graph_s* g, long rows, float* Y, const float* ZI, flo
                      float* PR, Step64Out out, void* hub_scratch, hipStream_t st) {
     GN_CHECK_ARG(rows < (1L << 24), "H=64 step kernel addresses rows with 32-bit byte offsets: rows=%ld >= 2^24 per launch "
                  "(split the batch)", rows);
+    // (the hub segment partials are addressed the same way: (sample * n_seg + segment) * 256 bytes)
+    GN_CHECK_ARG((long)(rows / g->n) * g->n_seg < (1L << 24), "H=64 step kernel addresses hub segment partials with 32-bit byte offsets: "
+                 "%ld samples x %d segments >= 2^24 per launch (split the batch)", (long)(rows / g->n), g->n_seg);
     const int tps = (g->n + 15) / 16;
     const long total = (long)(rows / g->n) * tps;
     const float* HubP = nullptr;               // per-segment partial sums of the hub rows; the step kernel adds them up itself

@@ -40,12 +40,12 @@ template <int LPR>
 __global__ __launch_bounds__(256) void k_hub_seg(const int* __restrict__ seg_lo, const int* __restrict__ seg_hi,
                                                  const int* __restrict__ col, int n, int n_seg, int H,
                                                  const float* __restrict__ T0, const float* __restrict__ T1,
-                                                 float* __restrict__ P0, float* __restrict__ P1) {
+                                                 float* __restrict__ P0, float* __restrict__ P1, long b0) {
     const int sub = threadIdx.x % LPR;
     const int s = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (s >= n_seg) return;
     const bool active = 4 * sub < H;
-    const long b = blockIdx.y;
+    const long b = b0 + blockIdx.y;                 // (grid.y is limited to 65 535: larger batches come as several launches)
     const float* t0 = T0 + (size_t)b * n * H;
     const float* t1 = T1 ? T1 + (size_t)b * n * H : nullptr;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
@@ -224,8 +224,11 @@ int gn_hub_segments2(const gnode_graph_s* g, long B, int H, const float* T0, con
     float* P0 = (float*)scratch;
     float* P1 = T1 ? (float*)((char*)scratch + part_b) : nullptr;       // (inside the two-table scratch of gn_hub_scratch_bytes)
     const int lpr = hub_lpr(H), gpw = 256 / lpr;
-    HUB_DISPATCH(lpr, hipLaunchKernelGGL(k_hub_seg<LPR>, dim3((unsigned)((g->n_seg + gpw - 1) / gpw), (unsigned)B), dim3(256), 0, st,
-                                         g->seg_lo, g->seg_hi, g->col, g->n, g->n_seg, H, T0, T1, P0, P1));
+    for (long b0 = 0; b0 < B; b0 += 65535) {
+        const unsigned nb = (unsigned)std::min<long>(65535, B - b0);
+        HUB_DISPATCH(lpr, hipLaunchKernelGGL(k_hub_seg<LPR>, dim3((unsigned)((g->n_seg + gpw - 1) / gpw), nb), dim3(256), 0, st,
+                                             g->seg_lo, g->seg_hi, g->col, g->n, g->n_seg, H, T0, T1, P0, P1, b0));
+    }
     GN_LAUNCH_CHECK();
     *P0out = P0;
     if (P1out) *P1out = P1;
@@ -248,8 +251,9 @@ int gn_hub_gather(const gnode_graph_s* g, long B, int H, const float* T0, const 
     float* P1 = (float*)(base + part_b + hub_b);
     float* a1 = (float*)(base + 2 * part_b + hub_b);
     const int lpr = hub_lpr(H), gpw = 256 / lpr;
+    GN_CHECK_ARG(B <= 65535, "hub sums: %ld samples per launch exceed the grid's y extent (split the batch)", B);
     HUB_DISPATCH(lpr, hipLaunchKernelGGL(k_hub_seg<LPR>, dim3((unsigned)((g->n_seg + gpw - 1) / gpw), (unsigned)B), dim3(256), 0, st,
-                                         g->seg_lo, g->seg_hi, g->col, g->n, g->n_seg, H, T0, T1, P0, P1));
+                                         g->seg_lo, g->seg_hi, g->col, g->n, g->n_seg, H, T0, T1, P0, P1, 0L));
     GN_LAUNCH_CHECK();
     HUB_DISPATCH(lpr, hipLaunchKernelGGL(k_hub_reduce<LPR>, dim3((unsigned)((g->n_hub + gpw - 1) / gpw), (unsigned)B), dim3(256), 0,
                                          st, g->hub_seg_ptr, g->n_hub, g->n_seg, H, P0, nt == 2 ? P1 : nullptr, a0, a1));

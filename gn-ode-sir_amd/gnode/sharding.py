@@ -34,10 +34,21 @@ def init_from_env():
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
             backend = os.environ.get("GNODE_DIST_BACKEND", "nccl")
+            if int(os.environ.get("LOCAL_WORLD_SIZE", world)) > torch.cuda.device_count():
+                share_device_guard()
         else:
             backend = "gloo"
         dist.init_process_group(backend)
     return world_info()
+
+
+def share_device_guard():
+    """Rehearsals that put several ranks on ONE GPU: the persistent one-launch kernels (csrc/gnode_pers64*.hip) need all of
+    their workgroups resident at once, one per CU, and two processes' launches could each hold half of the CUs while
+    waiting for the other half (their spins are bounded: a give-up code, not a hang).  One process per GPU is the
+    deployment; a shared device runs the one-launch-per-step forms."""
+    from . import ops
+    ops.PERSIST_DEFAULT = False
 
 
 def barrier():
@@ -109,3 +120,26 @@ def gather_rows(local: torch.Tensor, sizes):
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return torch.cat([b[:, :s] for b, s in zip(bufs, sizes)], dim=1)
+
+
+def sharded_forward(fn, x: torch.Tensor, gather: bool = True):
+    """BASELINE configs[3]'s pattern (inference over a batch of (beta, gamma, seed-set) samples on one graph): every rank
+    holds the whole batch x [B, n, ...] (or at least its own block), runs `fn` on its contiguous block of samples and --
+    `gather` -- every rank receives the full [G, B*n] outputs in sample order (ranks may own unequal blocks, or none).
+    fn(x_block) -> tuple of [G, rows_block] tensors.  No collective touches the data path itself."""
+    rank, world = world_info()
+    B, n = int(x.shape[0]), int(x.shape[1])
+    lo, hi = shard_range(B, rank, world)
+    outs = None
+    if hi > lo:
+        outs = tuple(fn(x[lo:hi]))
+    if world == 1 or not gather:
+        return outs
+    sizes = [(shard_range(B, r, world)[1] - shard_range(B, r, world)[0]) * n for r in range(world)]
+    # a rank with an empty block still takes part in the gathers: it needs the outputs' leading extent and dtype
+    meta = torch.tensor([len(outs), outs[0].shape[0]] if outs else [0, 0], dtype=torch.int64, device=x.device if x.is_cuda and dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX)
+    k, G = int(meta[0]), int(meta[1])
+    if outs is None:
+        outs = tuple(torch.zeros(G, 0, dtype=torch.float32, device=x.device) for _ in range(k))
+    return tuple(gather_rows(o, sizes) for o in outs)

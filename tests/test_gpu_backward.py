@@ -387,3 +387,26 @@ def test_training_gradient_vs_reference_classes(name, keep, dev, monkeypatch):
         if full:                                                              # yardstick: the reference's own fp32 run of the same rule
             print(f"[{name} {'kept' if keep else 'recompute'}] {k}: GPU vs reference float64 {err:.2e}; reference fp32 vs its float64 "
                   f"{_rel(d['G32:' + k], want):.2e}")
+
+
+def test_double_backward_through_one_forward(dev):
+    """loss.backward(retain_graph=True) twice through the same forward node: the kept activations stay
+    with the autograd context, so the second sweep sees the same buffers and gives the same gradient bits."""
+    import torch
+    import scipy.sparse as sp
+    from gnode import synth
+    from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
+    n, m, B, H = 300, 1200, 2, 64
+    rp, ci = synth.er_csr(n, m, seed=3)
+    A = sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n))
+    model = ODEBlock(6, 0.5, n, [0], H, ODEfunc(A, 0.2, 0.1, H, dev), dev).to(dev)
+    x = torch.from_numpy(synth.samples(n, B, H, seed=4)).to(dev)
+    S, I, R = model(x)
+    loss = (S * 0.3 + I * 0.5 - R * 0.2).sum()
+    loss.backward(retain_graph=True)
+    g1 = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    model.zero_grad()
+    loss.backward()
+    for k, v in model.named_parameters():
+        if v.grad is not None:
+            assert torch.equal(v.grad, g1[k]), k

@@ -43,6 +43,12 @@ def _worker(rank, world, port, q):
         S_all = sh.gather_rows(torch.from_numpy(S[..., 0]), sizes).numpy()
         S_ref, _, _ = O.odeblock_forward_single(x, P, rp, ci, maxTime, dT)
         ok_fwd = np.array_equal(S_all, S_ref[..., 0])
+        # the same through the configs[3] helper (unequal blocks: 3 + 2 samples), and with FEWER samples than ranks (rank 1 owns none)
+        fn = lambda xb: tuple(torch.from_numpy(a[..., 0]) for a in O.odeblock_forward_single(xb.numpy(), P, rp, ci, maxTime, dT))
+        got = sh.sharded_forward(fn, torch.from_numpy(x))
+        ok_fwd = ok_fwd and all(np.array_equal(g_.numpy(), r_[..., 0]) for g_, r_ in zip(got, O.odeblock_forward_single(x, P, rp, ci, maxTime, dT)))
+        got1 = sh.sharded_forward(fn, torch.from_numpy(x[:1]))
+        ok_fwd = ok_fwd and np.array_equal(got1[0].numpy(), O.odeblock_forward_single(x[:1], P, rp, ci, maxTime, dT)[0][..., 0])
         # ---- Monte-Carlo: sims range sharded, counts summed, row 0 restored
         sims, T = 37, 6
         slo, shi = sh.shard_range(sims, rank, world)
