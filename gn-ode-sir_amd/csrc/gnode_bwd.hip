@@ -1179,7 +1179,10 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     float* red = (float*)(ws + 8 * slab_b + 2 * vec_b + gn_align((size_t)BWD_NWG * L.total() * sizeof(float)));
     void* hub_scratch = ws + backward_fixed_bytes(rows, H);
     int slots_used = 1;                                  // highest workgroup slot any launch wrote, for the final reduction
-    const bool tiny = gn_tiny_bwd64_ok(g, rows, H, n_steps);
+    // what the forward that produced `sol` / `keep` was (its sol_info says so; unchecked callers: the same question, same flags)
+    const int n_emit = out_rows_host ? n_out : n_steps + 1;
+    const bool fwd_tiny = sol_info >= 0 ? (sol_info & GNODE_SOL_TINY) != 0 : gn_forward_kind(g, rows, H, 0, n_steps, n_emit, true, flags, nullptr) == 1;
+    const bool tiny = fwd_tiny && gn_tiny_bwd64_ok(g, rows, H, n_steps);
     if (tiny) {
         // graphs that fit one workgroup: the whole sweep is one launch writing slot b for sample b (gnode_bwd_tiny.hip)
         const size_t keep_need = gnode_forward_keep_bytes(g, rows, H, n_steps, out_rows_host ? n_out : n_steps + 1);
@@ -1230,7 +1233,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         // 16-row tiles at 3 workgroups per CU (measured on the 75k graph, 4 samples: 32-row tiles at 3 / 2 per CU 481 / 548 us
         // per interval, the unfused three-launch form 563; 16-row tiles 451)
         // does this trajectory carry A Z_I(y_i) in its 4th slabs (gnode_forward_f32 wrote it: H = 64, not the one-launch path)?
-        const bool ai_saved = gn_sol_carries_ai(g, H, n_steps, out_rows_host ? n_out : G);
+        const bool ai_saved = !fwd_tiny;               // the 4th slabs (or the keep buffer's P_S) carry A Z_I unless the one-workgroup forward ran
         // ... and did the forward keep Z_S(y_k), Z_I(y_k) as well?  Then the intervals below the last read them back
         const size_t keep_need = gnode_forward_keep_bytes(g, rows, H, n_steps, out_rows_host ? n_out : G);
         if (sol_info >= 0) {

@@ -322,7 +322,11 @@ static size_t tiny_bwd_lds_bytes(int n) {
     return sizeof(float) * ((size_t)2 * 64 * TS + (size_t)6 * nt * TILE_ROWS * TS);
 }
 
+#ifndef GN_TINY_TRAIN
+#define GN_TINY_TRAIN 1
+#endif
 bool gn_tiny_bwd64_ok(const gnode_graph_s* g, long rows, int H, int n_steps) {
+    if (!GN_TINY_TRAIN) return false;
     return H == 64 && g->n <= 2 * TILE_ROWS && n_steps >= 0 && n_steps <= 128 && rows / g->n <= BWD_NWG &&
            tiny_bwd_lds_bytes(g->n) <= 160 * 1024;
 }

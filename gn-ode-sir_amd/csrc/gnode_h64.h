@@ -12,7 +12,10 @@ struct Step64Out {
 
 // True when gnode_forward_f32 (H = 64, trajectory kept) stores A Z_I(y_k) in the 4th slab of sol[k], 1 <= k <= n_steps - 1,
 // instead of the beta-gamma copy; gnode_backward_f32 asks the same question about the `sol` it is handed.
-bool gn_sol_carries_ai(const gnode_graph_s* g, int H, int n_steps, int n_out);
+bool gn_sol_carries_ai(const gnode_graph_s* g, long rows, int H, int n_steps, int n_out, int flags);
+// 2 = persistent launch, 1 = one workgroup per sample, 0 = one launch per step (gnode_ode.hip); plan may be null
+struct PersPlan;
+int gn_forward_kind(const gnode_graph_s* g, long rows, int H, int method, int n_steps, int n_out, bool with_sol, int flags, PersPlan* plan);
 
 int gn_h64_set_attributes();    // once per device, from gnode_graph_create
 int gn_launch_mlp64(const gnode_graph_s* g, const float* X, const float* W, const float* b, float* Z, long nrows, hipStream_t st);

@@ -560,7 +560,11 @@ size_t gn_tiny64_lds_bytes(int n, bool prj) {
 }
 
 // true when the whole integration of one sample fits a workgroup (and the schedule fits the kernel arguments)
+#ifndef GN_TINY_TRAIN
+#define GN_TINY_TRAIN 1      // 0: training forwards (and the adjoint sweep) of tiny graphs take the persistent launches instead
+#endif
 bool gn_tiny64_ok(int n, int n_steps, int n_out, bool prj) {
+    if (!prj && !GN_TINY_TRAIN) return false;
     return n_steps >= 1 && n_steps <= 128 && n_out < 32768 && n <= 3 * TILE_ROWS &&
            gn_tiny64_lds_bytes(n, prj) <= 160 * 1024;
 }

@@ -652,6 +652,18 @@ extern "C" int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, co
 }
 
 // --------------------------------------------------------------------------- forward
+// Which form the H = 64 Euler forward takes for a batch: 2 = ONE persistent launch (gnode_pers64.hip; preferred wherever
+// its plan fits -- down to karate: it measured faster than the one-workgroup kernels, 0.11 vs 0.17 ms for 39 steps, and
+// its adjoint sweep 0.18 vs 0.35 ms), 1 = one workgroup per sample (tiny graphs in batches too large for one resident
+// grid), 0 = one launch per step.  The backward asks the same question (same arguments) to know what `sol` / `keep` hold.
+int gn_forward_kind(const gnode_graph_s* g, long rows, int H, int method, int n_steps, int n_out, bool with_sol, int flags, PersPlan* plan) {
+    if (!(H == 64 && method == 0) || n_steps < 1) return 0;
+    PersPlan pl;
+    if (!(flags & GNODE_FWD_PER_STEP) && gn_pers64_plan(g, rows / g->n, n_steps, &pl)) { if (plan) *plan = pl; return 2; }
+    if (gn_tiny64_ok(g->n, n_steps, n_out, !with_sol)) return 1;
+    return 0;
+}
+
 static size_t forward_fixed_bytes(int64_t rows, int32_t H, int32_t method) {
     const size_t slab = gn_align((size_t)rows * H * sizeof(float));
     size_t nslab = 5;                       // Y[3], Z[2]
@@ -706,7 +718,9 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
     }
     if (sol_info_host) {                         // what this call leaves in `sol` / `keep`: gnode_backward_f32 checks it
         const int n_emit = out_rows_host ? n_out : G;
-        *sol_info_host = !sol ? 0 : (keep ? GNODE_SOL_KEEP : (method == 0 && gn_sol_carries_ai(g, H, n_steps, n_emit) ? GNODE_SOL_AI : 0));
+        const int kind = gn_forward_kind(g, rows, H, method, n_steps, n_emit, sol != nullptr, flags, nullptr);
+        *sol_info_host = !sol ? 0 : ((keep ? GNODE_SOL_KEEP : (H == 64 && method == 0 && n_steps >= 1 && kind != 1 ? GNODE_SOL_AI : 0)) |
+                                     (kind == 1 ? GNODE_SOL_TINY : 0));
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t slab = (size_t)rows * H, slab_b = gn_align(slab * sizeof(float));
@@ -753,7 +767,21 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         if (method == 0 && H < 128 && n_steps > 0)
             if (int e = launch_mlp(g, Y + slab, p->odefunc_linear_weight, p->odefunc_linear_bias, zi_cur, rows, H, st)) return e;
     }
-    if (h64 && gn_tiny64_ok(g->n, n_steps, out_rows_host ? n_out : G, PR != nullptr)) {
+    PersPlan plan;
+    const int fkind = gn_forward_kind(g, rows, H, method, n_steps, out_rows_host ? n_out : G, sol != nullptr, flags, &plan);
+    if (fkind == 2) {
+        // mid-size graphs: ONE persistent launch, every workgroup keeps its rows in registers for all steps (gnode_pers64.hip)
+        int slots[128];
+        for (int k = 0; k < n_steps; ++k) slots[k] = out_slot(k + 1);
+        const bool sampled = prof_begin(0, st);
+        if (int e = gn_launch_pers64(g, plan, rows, Y, PR, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,
+                                     gamma, dt_host, slots, n_steps, p, S, I, R, sol, keep, forward_ctl_ptr(workspace, rows, H, method), st))
+            return e;
+        if (sampled) prof_mark(0, st);
+        return 0;
+    }
+
+    if (fkind == 1) {
         // tiny graphs: the whole integration in one launch (one workgroup per sample, state in LDS)
         int slots[128];
         for (int k = 0; k < n_steps; ++k) slots[k] = out_slot(k + 1);
@@ -767,19 +795,6 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         }
         return 0;
     }
-    PersPlan plan;
-    if (h64 && !(flags & GNODE_FWD_PER_STEP) && gn_pers64_plan(g, rows / g->n, n_steps, &plan)) {
-        // mid-size graphs: ONE persistent launch, every workgroup keeps its rows in registers for all steps (gnode_pers64.hip)
-        int slots[128];
-        for (int k = 0; k < n_steps; ++k) slots[k] = out_slot(k + 1);
-        const bool sampled = prof_begin(0, st);
-        if (int e = gn_launch_pers64(g, plan, rows, Y, PR, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,
-                                     gamma, dt_host, slots, n_steps, p, S, I, R, sol, keep, forward_ctl_ptr(workspace, rows, H, method), st))
-            return e;
-        if (sampled) prof_mark(0, st);
-        return 0;
-    }
-
     for (int k = 0; k < n_steps; ++k) {
         const float dt = dt_host[k];
         slot = out_slot(k + 1);
@@ -863,14 +878,10 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
 extern "C" int gnode_forward_path(gnode_graph_t g, int64_t rows, int32_t H, int32_t method, int32_t n_steps, int32_t n_out,
                                   int32_t with_sol, int32_t flags, int32_t* plan_host) {
     if (!g || rows <= 0 || rows % g->n) return -1;
-    if (!(H == 64 && method == 0) || n_steps < 1) return 0;
-    if (gn_tiny64_ok(g->n, n_steps, n_out, !with_sol)) return 1;
     PersPlan pl;
-    if (!(flags & GNODE_FWD_PER_STEP) && gn_pers64_plan(g, rows / g->n, n_steps, &pl)) {
-        if (plan_host) { plan_host[0] = pl.nt; plan_host[1] = pl.wgs; plan_host[2] = pl.span; plan_host[3] = pl.gpx; plan_host[4] = pl.concurrent; }
-        return 2;
-    }
-    return 0;
+    const int kind = gn_forward_kind(g, rows, H, method, n_steps, n_out, with_sol != 0, flags, &pl);
+    if (kind == 2 && plan_host) { plan_host[0] = pl.nt; plan_host[1] = pl.wgs; plan_host[2] = pl.span; plan_host[3] = pl.gpx; plan_host[4] = pl.concurrent; }
+    return kind;
 }
 
 // diagnostic build (GN_PERS_PROF): per-phase 100 MHz ticks of the last persistent launch on this workspace
@@ -899,11 +910,11 @@ extern "C" size_t gnode_forward_keep_bytes(gnode_graph_t g, int64_t rows, int32_
     return gn_keep_floats((long)rows, n_steps) * sizeof(float);
 }
 
-bool gn_sol_carries_ai(const gnode_graph_s* g, int H, int n_steps, int n_out) {
-    return H == 64 && n_steps >= 1 && !gn_tiny64_ok(g->n, n_steps, n_out, false);
+bool gn_sol_carries_ai(const gnode_graph_s* g, long rows, int H, int n_steps, int n_out, int flags) {
+    return H == 64 && n_steps >= 1 && gn_forward_kind(g, rows, H, 0, n_steps, n_out, true, flags, nullptr) != 1;
 }
 
-extern "C" int gnode_sol_carries_neighbour_sums(gnode_graph_t g, int32_t H, int32_t n_steps, int32_t n_out) {
-    if (!g) return 0;
-    return gn_sol_carries_ai(g, H, n_steps, n_out) ? 1 : 0;
+extern "C" int gnode_sol_carries_neighbour_sums(gnode_graph_t g, int64_t rows, int32_t H, int32_t n_steps, int32_t n_out, int32_t flags) {
+    if (!g || rows <= 0 || rows % g->n) return 0;
+    return gn_sol_carries_ai(g, rows, H, n_steps, n_out, flags) ? 1 : 0;
 }

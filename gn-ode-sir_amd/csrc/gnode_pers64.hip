@@ -343,7 +343,7 @@ bool gn_pers64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p) {
         const int wgs = (g->n + 16 * nt - 1) / (16 * nt);
         PersPlan q;
         q.nt = nt; q.wgs = wgs; q.n_xcc = n_xcc; q.slots = slots;
-        if (wgs <= slots) { q.span = 1; q.gpx = slots / wgs; q.per = wgs; q.concurrent = n_xcc * q.gpx; }
+        if (wgs <= slots) { q.span = 1; q.gpx = std::min(slots / wgs, PERS_FLAG_WORDS / 32 / n_xcc); q.per = wgs; q.concurrent = n_xcc * q.gpx; }   // (one 32-word flag line per group)
         else {
             int span = 2;
             while (span < n_xcc && wgs > span * slots) span *= 2;

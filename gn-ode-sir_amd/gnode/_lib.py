@@ -67,7 +67,7 @@ def load():
     lib.gnode_rhs_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, sz, vp]
     lib.gnode_forward_workspace_bytes.argtypes = [vp, i64, i32, i32]
     lib.gnode_forward_workspace_bytes.restype = sz
-    lib.gnode_sol_carries_neighbour_sums.argtypes = [vp, i32, i32, i32]
+    lib.gnode_sol_carries_neighbour_sums.argtypes = [vp, i64, i32, i32, i32, i32]
     lib.gnode_sol_carries_neighbour_sums.restype = C.c_int
     lib.gnode_forward_keep_bytes.argtypes = [vp, i64, i32, i32, i32]
     lib.gnode_forward_keep_bytes.restype = sz

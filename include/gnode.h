@@ -105,8 +105,8 @@ int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* 
  *              returns (needed by the adjoint backward, never by inference).
  *              Slabs S, I, R of every grid point are odeint's.  The 4th slab
  *              (beta, gamma; derivative 0, so odeint repeats sol[0]'s at every grid
- *              point) is odeint's at grid point 0 everywhere; at H = 64 (the fused
- *              path, graphs that do not fit the one-launch kernel) grid points
+ *              point) is odeint's at grid point 0 everywhere; at H = 64 (every form but the
+ *              one-workgroup-per-sample launch, gnode_forward_path() == 1) grid points
  *              1 .. n_steps-1 carry A*Z_I(y_k) there instead -- the neighbour sums
  *              the adjoint backward would otherwise gather a second time -- when no
  *              `keep` buffer is given, and are left UNWRITTEN when one is (the sums then
@@ -139,9 +139,10 @@ int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* 
 #define GNODE_FWD_PER_STEP 1
 #define GNODE_SOL_AI 1
 #define GNODE_SOL_KEEP 2
+#define GNODE_SOL_TINY 4   /* produced by the one-workgroup-per-sample forward: no A*Z_I anywhere, keep holds the sigmoids only */
 size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t method);
-/* Which form gnode_forward_f32 runs for this shape: 0 = one launch per step, 1 = the one-workgroup-per-sample launch of
- * tiny graphs, 2 = the persistent launch of mid-size graphs (then plan_host, if given, receives {16-row tiles per
+/* Which form gnode_forward_f32 runs for this shape: 0 = one launch per step, 1 = the one-workgroup-per-sample launch (tiny
+ * graphs in batches too large for one resident grid), 2 = the persistent launch (tiny and mid-size graphs) (then plan_host, if given, receives {16-row tiles per
  * workgroup, workgroups per sample, XCDs per sample, samples side by side per XCD, samples alive at once}); -1 = bad
  * arguments.  n_out: emitted grid points; with_sol: a trajectory is requested (training). */
 int gnode_forward_path(gnode_graph_t g, int64_t rows, int32_t H, int32_t method, int32_t n_steps, int32_t n_out,
@@ -153,7 +154,7 @@ int gnode_forward_status(int64_t rows, int32_t H, int32_t method, const void* wo
 /* 1 when gnode_forward_f32 (method 0, no `keep` buffer) on this graph stores A*Z_I(y_k) in the 4th slab of sol[k],
  * 1 <= k <= n_steps-1 (see `sol` below), 0 when the 4th slab repeats beta, gamma at every grid point.  n_out: number
  * of emitted grid points (n_steps+1 when out_rows_host is NULL). */
-int gnode_sol_carries_neighbour_sums(gnode_graph_t g, int32_t H, int32_t n_steps, int32_t n_out);
+int gnode_sol_carries_neighbour_sums(gnode_graph_t g, int64_t rows, int32_t H, int32_t n_steps, int32_t n_out, int32_t flags);
 /* Size of the optional `keep` buffer of gnode_forward_f32 / gnode_backward_f32 (method 0), or 0 when this H keeps
  * nothing (then pass NULL).  3 * (n_steps + 1) * (rows + 1) * H floats at H = 64 (the tiled and the one-launch form). */
 size_t gnode_forward_keep_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t n_steps, int32_t n_out);

@@ -483,7 +483,10 @@ def test_tiny_graphs_and_small_hidden(n, edges, B, H, dev):
     So, Io, Ro, sol_o = O.odeblock_forward_single(x, P, rp, ci, 4, 0.5, return_sol=True)
     for got, w in zip((S, I, R), (So, Io, Ro)):
         assert _rel(got.cpu().numpy(), w[..., 0]) <= RTOL
-    assert _rel(sol.cpu().numpy(), sol_o) <= RTOL
+    q = 3 * B * n                                   # (H = 64: the 4th slabs past grid point 0 are not odeint's, include/gnode.h)
+    assert _rel(sol.cpu().numpy()[:, :q], sol_o[:, :q]) <= RTOL and np.array_equal(sol.cpu().numpy()[0, q:], sol_o[0, q:])
+    if H != 64:
+        assert _rel(sol.cpu().numpy(), sol_o) <= RTOL
     S2, _, _, _ = ops.forward(g, torch.from_numpy(x).to(dev).reshape(B * n, 3 + H), _tp(P, dev),
                               ops.step_sizes(ops.time_grid(4, 0.5)))
     assert _rel(S2.cpu().numpy(), So[..., 0]) <= RTOL
@@ -626,7 +629,7 @@ def test_randomized_configurations(dev):
             q, sol_h = 3 * B * n, sol.cpu().numpy()
             assert _rel(sol_h[:, :q], sol_o[:, :q]) <= RTOL, tag
             assert np.array_equal(sol_h[0, q:], sol_o[0, q:]), tag
-            carries = _lib.load().gnode_sol_carries_neighbour_sums(g.handle, H, G - 1, len(idx)) if method == "euler" else 0
+            carries = _lib.load().gnode_sol_carries_neighbour_sums(g.handle, B * n, H, G - 1, len(idx), 0 if ops.PERSIST_DEFAULT else 1) if method == "euler" else 0
             if not carries:      # odeint's own 4th slab at every grid point (the fused H = 64 path keeps A Z_I there instead:
                 assert np.array_equal(sol_h[:, q:], sol_o[:, q:]), tag      # test_forward_sol_matches_states)
 

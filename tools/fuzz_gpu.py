@@ -27,6 +27,7 @@ def main():
     torch.manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)      # the cotangents are part of the case
     worst = 0.0
     worst_f = 0.0
+    n_pers = 0
     for c in range(cases):
         n = int(rng.choice([5, 20, 33, 34, 62, 64, 65, 66, 97, 127, 128, 129, 255, 257, 511, 1000, 1893, 4097, 7066, int(rng.integers(65, 9000))]))
         B = int(rng.integers(1, 10))
@@ -49,12 +50,51 @@ def main():
         g = DeviceGraph(rp, ci)
         Pt = {k: torch.from_numpy(v).to(dev) for k, v in P.items()}
         x2d = torch.from_numpy(x).to(dev).reshape(B * n, 3 + H)
+        rows = B * n
         S1, I1, R1, sol1 = ops.forward(g, x2d, Pt, dts, "euler", out_rows, want_sol=True)
         S0, I0, R0, sol0 = ops.forward(g, x2d, Pt, dts, "euler", out_rows, want_sol=True, want_keep=False)
-        rows = B * n
         assert torch.equal(S1, S0) and torch.equal(I1, I0) and torch.equal(R1, R0), (c, "outputs differ with keep")
         # forward (inference path: projected R, no trajectory) and training forward against the C restatement of the reference
         Si, Ii, Ri, _ = ops.forward(g, x2d, Pt, dts, "euler", out_rows)
+        assert ops.forward_status() == 0, (c, "a persistent launch gave up")
+        # the persistent one-launch path (where the plan takes it) against one launch per step: bit for bit, inference and training
+        if ops.forward_path(g, rows, H, n_steps, n_out)[0] == 2:
+            Sp, Ip, Rp, _ = ops.forward(g, x2d, Pt, dts, "euler", out_rows, persist=False)
+            if ops.forward_path(g, rows, H, n_steps, n_out, persist=False)[0] == 0:
+                assert torch.equal(Si, Sp) and torch.equal(Ii, Ip) and torch.equal(Ri, Rp), (c, "persistent != per-step (inference)", n, B, n_steps)
+            else:      # the one-workgroup kernels chain their matrix products differently: fp32 rounding, not bits
+                assert max(float((a_ - b_).abs().max()) for a_, b_ in ((Si, Sp), (Ii, Ip), (Ri, Rp))) <= 2e-6, (c, "persistent vs one-workgroup", n, B, n_steps)
+            n_pers += 1
+        if ops.forward_path(g, rows, H, n_steps, n_out, want_sol=True)[0] == 2:
+            St, It, Rt, solt = ops.forward(g, x2d, Pt, dts, "euler", out_rows, want_sol=True, persist=False)
+            if ops.forward_path(g, rows, H, n_steps, n_out, want_sol=True, persist=False)[0] == 0:
+                assert torch.equal(S1, St) and torch.equal(sol1[:, :3 * rows], solt[:, :3 * rows]), (c, "persistent != per-step (training)", n, B, n_steps)
+            else:
+                assert float((sol1[:, :3 * rows] - solt[:, :3 * rows]).abs().max()) <= 2e-5 * max(1.0, float(solt[:, :3 * rows].abs().max())), (c, "persistent vs one-workgroup (training)")
+            gq = [torch.randn(n_out, rows, device=dev) for _ in range(3)]     # (equal cotangents would make every exact gradient 0: S + I + R = 1)
+            at = ops.backward(g, x2d, Pt, dts, "euler", out_rows, solt, *gq, persist=False)
+            ap = ops.backward(g, x2d, Pt, dts, "euler", out_rows, sol1, *gq, persist=True)
+            for k in at:
+                if k != "linearS2.bias":
+                    # (two fp32 sweeps that add rows up in different orders: the suite's bar against float64, 2e-4 of the gradient's
+                    #  scale; tensors that are sums of cancelling terms are measured against the largest gradient's scale)
+                    sc_ = max(float(at[k].abs().max()), 1e-1 * max(float(v.abs().max()) for v in at.values())) + 1e-30
+                    if float((at[k] - ap[k]).abs().max()) / sc_ > 2e-4:
+                        want = O.adjoint_grads_torch(x, P, rp, ci, (n_steps + 1) * 0.5, 0.5, *[t.cpu().numpy() for t in gq], out_rows=out_rows, dtype="float64")
+                        print(f"case {c}: persistent sweep vs per-interval, n={n} B={B} steps={n_steps} out_rows={None if out_rows is None else out_rows.tolist()} "
+                              f"fwd kinds {ops.forward_path(g, rows, H, n_steps, n_out, want_sol=True)} / {ops.forward_path(g, rows, H, n_steps, n_out, want_sol=True, persist=False)}", flush=True)
+                        for kk in at:
+                            ww = np.asarray(want[kk]); scw = np.abs(ww).max() + 1e-30
+                            print(f"  {kk:24s} |want| {scw:.3e}  persistent-f64 {np.abs(ap[kk].cpu().numpy() - ww).max() / scw:.2e}  per-interval-f64 {np.abs(at[kk].cpu().numpy() - ww).max() / scw:.2e}", flush=True)
+                        # ill-conditioned cases (e.g. only grid point 0 emitted: every ODE gradient is exactly 0 and the head's are sums
+                        # of cancelling terms): hold the persistent sweep to the per-interval path's own distance from float64
+                        gw = max(np.abs(np.asarray(v)).max() for v in want.values())
+                        for kk in at:
+                            if kk == "linearS2.bias": continue
+                            ww = np.asarray(want[kk]); scw = max(np.abs(ww).max(), 1e-1 * gw) + 1e-30
+                            ea_, er_ = np.abs(ap[kk].cpu().numpy() - ww).max() / scw, np.abs(at[kk].cpu().numpy() - ww).max() / scw
+                            assert ea_ <= max(2e-4, 1.5 * er_), (c, "persistent sweep off", kk, ea_, er_, n, B, n_steps)
+                        break
         Sc, Ic, Rc = OC.forward_euler(rp, ci, n, x, P, dts)
         sel = np.arange(G) if out_rows is None else out_rows
         ref64 = None
@@ -109,6 +149,7 @@ def main():
         torch.cuda.synchronize()
         if c % 5 == 0:
             print(f"case {c}: n={n} B={B} steps={n_steps} keep={'yes' if sol1.gnode_keep is not None else 'no'} worst so far {worst:.2e}", flush=True)
+    print(f"{n_pers} cases took the persistent path (bit-identical to one launch per step)")
     print(f"OK {cases} cases, worst kept-vs-recomputed {worst:.2e}, worst forward-vs-C-oracle {worst_f:.2e}")
 
 
