@@ -1195,8 +1195,8 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
             return e;
         slots_used = (int)(rows / g->n);
     } else {
-    GN_HIP(hipMemsetAsync(a, 0, 3 * slab * sizeof(float), st));
-    GN_HIP(hipMemsetAsync(part, 0, (size_t)BWD_NWG * L.total() * sizeof(float), st));
+    if (int e = gn_zero_async(a, 3 * slab * sizeof(float), st)) return e;
+    if (int e = gn_zero_async(part, (size_t)BWD_NWG * L.total() * sizeof(float), st)) return e;
     hipLaunchKernelGGL(k_extract_bg, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, sol + 3 * slab, (long)rows, H,
                        beta, gamma);
     GN_LAUNCH_CHECK();
@@ -1225,7 +1225,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         // one launch per interval: a[3] | Z_S | Z_I(0) | q(0) | Z_I(1) | q(1)  (Z_S is row-local, the gather tables ping-pong)
         float* ZS = Z; float* ZIb[2] = {Z + slab, dpre};     // (k_mlp64_q fills Z_S | Z_I element-contiguously)
         float* Qb[2] = {q, dpre + slab_b / sizeof(float)};
-        for (int k = 0; k < 2; ++k) GN_HIP(hipMemsetAsync(Qb[k] + slab, 0, (size_t)H * sizeof(float), st));   // the q tables' zero rows
+        for (int k = 0; k < 2; ++k) if (int e = gn_zero_async(Qb[k] + slab, (size_t)H * sizeof(float), st)) return e;   // the q tables' zero rows
         const long mt = (2 * rows + TILE_ROWS - 1) / TILE_ROWS;
         hipLaunchKernelGGL(k_mlp64_q, dim3((unsigned)std::min<long>(mt, 1024)), dim3(256), 0, st, sol + (size_t)(G - 1) * 4 * slab,
                            p->odefunc_linear_weight, p->odefunc_linear_bias, Z, a, beta, q, (long)rows);

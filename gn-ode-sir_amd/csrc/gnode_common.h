@@ -75,6 +75,11 @@ template <class T> __host__ __device__ static inline T* gn_keep_ps(T* keep, long
 
 void gnode_set_error(const char* fmt, ...);
 
+// Zero `bytes` (a multiple of 4) at `p` (4-byte aligned) on the stream, with a KERNEL: hipMemsetAsync becomes a memset node when a
+// caller captures the call into a HIP graph, and on this ROCm such nodes were not re-executed reliably on the second and later
+// replays (round 3: the trainer's replayed step summed stale gradient slots).  Kernel nodes replay in order.
+int gn_zero_async(void* p, size_t bytes, hipStream_t st);
+
 // opt-in launch profiler (gnode_profile_enable): bracket a launch of `kind` with HIP events when it is sampled
 bool gn_prof_begin(int kind, hipStream_t st);
 void gn_prof_end(int kind, hipStream_t st);

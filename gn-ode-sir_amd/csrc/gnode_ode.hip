@@ -26,6 +26,23 @@ void gnode_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gnode_last_error(void) { return g_err; }
+
+__global__ __launch_bounds__(256) void k_zero_words(uint32_t* __restrict__ p, size_t nwords) {
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < nwords; i += stride) {
+        if (i + 4 <= nwords && ((uintptr_t)(p + i) & 15u) == 0) *reinterpret_cast<uint4*>(p + i) = make_uint4(0u, 0u, 0u, 0u);
+        else for (size_t j = i; j < nwords && j < i + 4; ++j) p[j] = 0u;
+    }
+}
+int gn_zero_async(void* p, size_t bytes, hipStream_t st) {
+    GN_CHECK_ARG(bytes % 4 == 0 && ((uintptr_t)p & 3u) == 0, "gn_zero_async: unaligned region");
+    if (bytes == 0) return 0;
+    const size_t nwords = bytes / 4;
+    const unsigned grid = (unsigned)std::min<size_t>((nwords / 4 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(k_zero_words, dim3(grid), dim3(256), 0, st, (uint32_t*)p, nwords);
+    GN_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int gnode_version(void) { return 220; }   // 220: forward takes flags + reports what sol / keep carry (sol_info), backward checks it; persistent one-launch path for mid-size graphs; 200: workspace sizes take the graph handle (hub scratch is carved from the caller's workspace); 210: forward / backward take the optional kept-activation buffer
 
 // --------------------------------------------------------------------------- instrumentation
@@ -647,7 +664,7 @@ extern "C" int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, co
     if (int e = launch_gather(g, 0, rows, H, const_cast<float*>(x), Z, x + 3 * slab, x + 3 * slab + 1, H, 0.f, dx,
                               nullptr, none, hub_scratch, st))
         return e;
-    GN_HIP(hipMemsetAsync(dx + 3 * slab, 0, slab * sizeof(float), st));  // 4th slab derivative = 0 (:96)
+    if (int e = gn_zero_async(dx + 3 * slab, slab * sizeof(float), st)) return e;   // 4th slab derivative = 0 (:96)
     return 0;
 }
 

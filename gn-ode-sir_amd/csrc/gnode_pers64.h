@@ -11,7 +11,7 @@
 //   concurrent  groups alive at once (>= B: one round)
 struct PersPlan { int nt, wgs, span, gpx, per, slots, n_xcc, rounds, concurrent, fstride; };
 
-struct PersCtl {                       // device memory, zeroed by a memset node in front of every launch
+struct PersCtl {                       // device memory, zeroed (k_pers_zero) in front of every launch
     unsigned ticket[8][32];            // per XCC (a 128-B line each): the next free slot on that XCD
     unsigned error[32];                // [0] != 0: a workgroup gave up waiting (code), [1]: the epoch it waited for
     unsigned flags[PERS_FLAG_WORDS];   // per group `fstride` words: workgroup idx's last published epoch
@@ -43,6 +43,7 @@ struct PersArgs {
 // false: this (graph, batch, horizon) does not take the persistent path (hub rows, too many rows for one resident grid, ...)
 bool gn_pers64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p);
 size_t gn_pers64_ctl_bytes();
+int gn_pers64_zero_ctl(void* ctl, hipStream_t st);      // in front of every persistent launch (a kernel: see gnode_pers64.hip)
 int gn_pers64_set_attributes();
 // Y0 / PR0 / beta / gamma / table 0 (Z0, or keep's first table) as gn_launch_prologue64 left them
 int gn_launch_pers64(const gnode_graph_s* g, const PersPlan& pl, long rows, const float* Y0, const float* PR0, float* Z0, float* Z1,

@@ -362,6 +362,11 @@ bool gn_pers64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p) {
 
 size_t gn_pers64_ctl_bytes() { return gn_align(sizeof(PersCtl)); }
 
+// Tickets, flags and the give-up word are zeroed in front of EVERY persistent launch -- by a kernel, not by hipMemsetAsync (see
+// gn_zero_async: under graph replay the memset node left the tickets counting on, every workgroup found itself idle, and the
+// trainer's replayed step either "ran" in 0.2 ms on stale outputs or waited out the 2 s give-up).
+int gn_pers64_zero_ctl(void* ctl, hipStream_t st) { return gn_zero_async(ctl, sizeof(PersCtl), st); }
+
 static size_t pers_lds_bytes(int nt, int partial_slots = PERS_MAX_PARTIALS) {
     const size_t need = sizeof(float) * ((size_t)64 * TS + 256 + 16 + (size_t)nt * 4 * 16 * TS + (size_t)partial_slots * 96 + (size_t)16 * nt * PERS_MAX_ITEMS);
     return std::max<size_t>(need, 84 * 1024);              // > half of the CU's 160 KB: ONE workgroup per CU
@@ -392,7 +397,7 @@ int gn_launch_pers64(const gnode_graph_s* g, const PersPlan& pl, long rows, cons
     a.S = S; a.I = I; a.R = R; a.sol = sol; a.ctl = (PersCtl*)ctl;
     a.sched.n_steps = n_steps;
     for (int k = 0; k < n_steps; ++k) { a.sched.dt[k] = dt_host[k]; a.sched.slot[k] = (short)slot_host[k]; }
-    GN_HIP(hipMemsetAsync(ctl, 0, sizeof(PersCtl), st));  // tickets, flags, give-up word: zeroed before EVERY launch (a memset node under capture)
+    if (int e = gn_pers64_zero_ctl(ctl, st)) return e;     // tickets, flags, give-up word: zeroed before EVERY launch
     const bool prj = PR0 != nullptr, sc1 = pl.span > 1;
     const dim3 grid((unsigned)(pl.n_xcc * pl.slots));
 #define PS_GO(P, N, S) { if (hubs) hipLaunchKernelGGL((k_pers64<P, N, S, true>), grid, dim3(256 * N), pers_lds_bytes(N, g->perslds[vi]), st, a); \

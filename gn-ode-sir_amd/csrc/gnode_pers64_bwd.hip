@@ -295,7 +295,7 @@ int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, 
     // samples are independent: batches beyond what one resident grid holds run as consecutive launches of `concurrent` samples
     for (int b0 = 0; b0 < x.B; b0 += pl.concurrent) {
         x.b0 = b0;
-        GN_HIP(hipMemsetAsync(ctl, 0, sizeof(PersCtl), st));
+        if (int e = gn_pers64_zero_ctl(ctl, st)) return e;
 #define PB_GO(N, S) { if (hubs) hipLaunchKernelGGL((k_pers_bwd64<N, S, true>), grid, dim3(256 * N), pers_bwd_lds_bytes(N, g->perslds[vi]), st, x); \
                       else hipLaunchKernelGGL((k_pers_bwd64<N, S, false>), grid, dim3(256 * N), pers_bwd_lds_bytes(N, 0), st, x); }
         if (pl.nt == 1) { if (sc1) PB_GO(1, true) else PB_GO(1, false) }

@@ -508,7 +508,7 @@ static int sir_mc_philox_impl(gnode_graph_t g, const int32_t* seeds_host, int32_
     int32_t* src = (int32_t*)(ws + hist_b + gn_align(4096 * sizeof(int32_t)));
     uint8_t* gstate = (uint8_t*)(ws + hist_b + gn_align(4096 * sizeof(int32_t)) +
                                  gn_align((size_t)std::max<int64_t>(g->nnz, 1) * sizeof(int32_t)));
-    GN_HIP(hipMemsetAsync(hist, 0, hist_b, st));
+    if (int e = gn_zero_async(hist, hist_b, st)) return e;
     // seed ids: up to 32 travel as a kernel argument (no copy, no synchronisation -- the reference's experiments use 2);
     // longer lists are copied from the caller's host array, which may be a temporary, so the stream is synchronised
     // before returning control (documented in gnode.h)

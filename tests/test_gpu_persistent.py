@@ -145,3 +145,51 @@ def test_sol_info_pairing_is_checked(dev):
     sol_k.gnode_keep = keep
     ops.backward(g, x, P, dts, "euler", None, sol_k, *gs)
     ops.backward(g, x, P, dts, "euler", None, sol_n, *gs)
+
+
+@pytest.mark.parametrize("n,m", [(34, 78), (1893, 13835)])
+def test_persistent_training_step_under_graph_replay(n, m, dev):
+    """forward + loss + adjoint sweep captured into ONE HIP graph (what the trainer does) and replayed several times: every
+    replay must re-run the persistent launches (fresh tickets and flags -- they are zeroed by a kernel node: a memset node was
+    not re-executed correctly on the second replay) and reproduce the eager gradient bits."""
+    import torch
+    import scipy.sparse as sp
+    from gnode import ops, synth
+    from gnode.autograd import l1_loss_sum
+    from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
+    H, maxTime = 64, 20
+    rp, ci = synth.er_csr(n, m, seed=1)
+    A = sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n))
+    model = ODEBlock(maxTime, 0.5, n, [0], H, ODEfunc(A, 0.2, 0.1, H, dev), dev).to(dev)
+    x = torch.from_numpy(synth.samples(n, 1, H, seed=2)).to(dev)
+    y = torch.from_numpy(np.random.default_rng(0).dirichlet(np.ones(3), size=(n, maxTime))).to(dev)
+    rows = ops.subsample_rows(maxTime, 0.5)
+    assert ops.forward_path(model.odefunc.graph, n, H, 2 * maxTime - 1, len(rows), want_sol=True)[0] == 2
+
+    def step():
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        S, I, R = model(x, out_rows=rows)
+        l1_loss_sum(S, I, R, y, 1).backward()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    want = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for rep in range(4):
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert ops.forward_status() == 0, rep
+        for k, v in model.named_parameters():
+            if v.grad is not None:
+                assert torch.equal(v.grad, want[k]), (rep, k)
