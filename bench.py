@@ -20,6 +20,7 @@ Besides the contract's keys the JSON line carries (rank 0, N = 1 only; none of i
                 and the check of the TIMED GPU outputs against that C restatement (`outputs_checked`)
   train         forward + adjoint backward + Adam, ms per step, on configs[1]'s shape and on the 75k graph x 4, each with a
                 gradient check (default path vs the recomputing per-interval path; configs[1]: vs the reference-class fixture)
+  tiny          configs[0] (karate size, batch 1: the reference's shipped experiment): forward, trainer step eager / HIP graph
   mid           the reference's REAL regime (monitorer-sim.py:10: batch_size 1; fb-social / wiki-vote sizes) on graphs with
                 those datasets' degree tails: forward and training step at B = 1, persistent one-launch path vs one launch
                 per Euler step
@@ -326,6 +327,45 @@ def bench_mid(lib, dev):
         rec["limiter"] = "latency: per step one group barrier (~2 us flag flight) + one gather round trip (~1 us) + the hub segments' round trips"
         out[name] = rec
         del model, x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_tiny(lib, dev):
+    """configs[0]: karate size (34 nodes, 78 edges), hidden 64, maxTime 20, batch_size 1 -- the reference's shipped default
+    experiment (monitorer-sim.py:10-22): inference forward, and the trainer's step (forward + L1 loss + adjoint sweep + Adam) as
+    the drop-in scripts run it: eager launches and HIP-graph replay."""
+    import scipy.sparse as sp
+    import torch
+    from gnode import ops, synth
+    from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
+    from gnode.trainer import Runner
+    n, m, H, maxTime, deltaT = 34, 78, 64, 20, 0.5
+    rp, ci = synth.er_csr(n, m, seed=1)
+    A = sp.csr_matrix((np.ones(ci.shape[0]), ci, rp), shape=(n, n))
+    model = ODEBlock(maxTime, deltaT, n, [0], H, ODEfunc(A, 0.2, 0.1, H, dev), dev).to(dev)
+    x1 = torch.from_numpy(synth.samples(n, 1, H, seed=2)).to(dev)
+    n_steps = len(ops.time_grid(maxTime, deltaT)) - 1
+
+    def fwd():
+        with torch.no_grad():
+            model(x1)
+
+    out = {"shape": f"ER n={n} nnz={int(ci.shape[0])} B=1 H={H} {n_steps} Euler steps", "forward_ms": _ev_ms(fwd, 30),
+           "path": {0: "one launch per Euler step", 1: "one-workgroup launch", 2: "persistent one-launch"}[ops.forward_path(model.odefunc.graph, n, H, n_steps)[0]]}
+    xs = [x1.cpu()[0]] * 8
+    ys = [torch.from_numpy(np.random.default_rng(0).dirichlet(np.ones(3), size=(n, maxTime)))] * 8
+    for mode in (False, True):
+        run = Runner(model, 1e-3, maxTime, deltaT, dev, stack=True, use_graphs=mode)
+        xp, yp = run.place(xs, ys)
+        run.train_epoch(xp, yp, 1, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for ep in range(3):
+            run.train_epoch(xp, yp, 1, ep)
+        torch.cuda.synchronize()
+        out["trainer_step_%s_ms" % ("hip_graph" if mode else "eager")] = (time.perf_counter() - t0) / (3 * 8) * 1e3
+    del model
     torch.cuda.empty_cache()
     return out
 
@@ -647,6 +687,7 @@ def main():
             result["train"] = {"configs[1] shape": bench_train(lib, dev, 1893, 13835, 8, 64, 30, 0.5, 10),
                                "75k graph x 4": bench_train(lib, dev, 75000, 500000, 4, 64, 30, 0.5, 3)}
             result["train"]["configs[1] shape"]["gradient_vs_reference_classes"] = reference_fixture_gradient(dev)
+            result["tiny"] = bench_tiny(lib, dev)
             result["mid"] = bench_mid(lib, dev)
             result["h8"] = bench_h8(lib, dev)
             result["sir"], sir_ctx = bench_sir(lib, dev, 7066, 100736, 10000, 20)
