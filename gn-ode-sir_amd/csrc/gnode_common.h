@@ -32,6 +32,7 @@ struct gnode_graph_s {
     int32_t* perssegptr[3];
     int32_t* perssegitem[3];
     int32_t perslds[3];
+    int32_t persitems[3];   // most segment sums any one lane group was given (rounds of 32-row gathers the step waits for)
 };
 
 #define HUB_SEG 32           // a hub row's neighbour list is cut into segments of this many edges

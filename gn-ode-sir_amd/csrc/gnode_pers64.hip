@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
 static const int kPersMaxRows = 256 * 64;              // one resident grid: 256 workgroups x 64 rows
 #define PERS_MAX_PARTIALS 128                          // partial-sum slots (256 B each) a workgroup may need for its hub rows
 int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host) {
-    for (int i = 0; i < 3; ++i) { g->persmap[i] = g->pershub[i] = g->perssegptr[i] = g->perssegitem[i] = nullptr; g->perslds[i] = 0; }
+    for (int i = 0; i < 3; ++i) { g->persmap[i] = g->pershub[i] = g->perssegptr[i] = g->perssegitem[i] = nullptr; g->perslds[i] = 0; g->persitems[i] = 0; }
     if (g->n > kPersMaxRows) return 0;
     std::vector<int32_t> order((size_t)g->n);
     for (int32_t r = 0; r < g->n; ++r) order[r] = r;
@@ -283,7 +283,7 @@ int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host) {
         // hub rows: the segments of a workgroup's hubs are summed by that workgroup's own lane groups (partials through LDS),
         // dealt to the lane groups with the least gather work so far; a hub's partial slots are consecutive, in segment order
         std::vector<int32_t> hub((size_t)wgs * per_wg * 2, 0), segptr((size_t)wgs * per_wg * 2, 0), items;
-        int max_slots = 0;
+        int max_slots = 0, max_items = 0;
         bool ok = true;
         for (int wg = 0; wg < wgs && ok; ++wg) {
             std::vector<long> load((size_t)per_wg, 0);
@@ -308,7 +308,7 @@ int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host) {
                 }
             }
             if (slots > PERS_MAX_PARTIALS) ok = false;
-            for (int s = 0; s < per_wg; ++s) if (mine[s].size() / 4 > PERS_MAX_ITEMS) ok = false;
+            for (int s = 0; s < per_wg; ++s) { if (mine[s].size() / 4 > PERS_MAX_ITEMS) ok = false; max_items = std::max(max_items, (int)(mine[s].size() / 4)); }
             max_slots = std::max(max_slots, slots);
             for (int s = 0; s < per_wg; ++s) {
                 segptr[((size_t)wg * per_wg + s) * 2] = (int32_t)(items.size() / 4);
@@ -322,6 +322,7 @@ int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host) {
         GN_HIP(up(&g->perssegptr[i], segptr));
         GN_HIP(up(&g->perssegitem[i], items));
         g->perslds[i] = max_slots;
+        g->persitems[i] = max_items;
     }
     return 0;
 }
@@ -338,8 +339,13 @@ bool gn_pers64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p) {
     if (g->num_cu < 64 || g->num_cu % n_xcc) return false;
     const int slots = g->num_cu / n_xcc;
     if ((long)B * g->n >= (1L << 24)) return false;
+    // the smallest tile count that holds the batch -- except that a graph whose biggest hub would give a lane group TWO segment
+    // sums per step (a second ~2 us round of 32-row gathers every step) takes the next tile count when that halves the rounds
+    // (fb-social size with a 738-edge row, B = 1: 8.7 -> 7.x us per step at 32 instead of 16 rows per workgroup)
+    bool have = false;
     for (int nt = 1; nt <= 4; nt *= 2) {
-        if (!g->persmap[nt == 1 ? 0 : nt == 2 ? 1 : 2]) continue;      // graph too large, or its hub rows need too many partial slots
+        const int vi = nt == 1 ? 0 : nt == 2 ? 1 : 2;
+        if (!g->persmap[vi]) continue;      // graph too large, or its hub rows need too many partial slots
         const int wgs = (g->n + 16 * nt - 1) / (16 * nt);
         PersPlan q;
         q.nt = nt; q.wgs = wgs; q.n_xcc = n_xcc; q.slots = slots;
@@ -354,10 +360,10 @@ bool gn_pers64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p) {
         q.rounds = 1;
         q.fstride = (wgs + 31) / 32 * 32;
         if ((long)q.concurrent * q.fstride > PERS_FLAG_WORDS) continue;
-        *p = q;
-        return true;
+        if (!have) { *p = q; have = true; if (g->persitems[vi] <= 1) return true; continue; }
+        if (nt <= 2 && g->persitems[vi] < g->persitems[p->nt == 1 ? 0 : 1]) { *p = q; if (g->persitems[vi] <= 1) return true; }
     }
-    return false;
+    return have;
 }
 
 size_t gn_pers64_ctl_bytes() { return gn_align(sizeof(PersCtl)); }
