@@ -29,6 +29,7 @@
 #include "gnode_mfma64.h"
 #include "gnode_head64.h"
 #include "gnode_pers64.h"
+#include "gnode_persg.h"
 #include <algorithm>
 
 __device__ __forceinline__ float4 ld4b(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -1128,7 +1129,7 @@ static size_t backward_fixed_bytes(int64_t rows, int32_t H) {
     // (+ the control block of the persistent sweep, gnode_pers64_bwd.hip)
     return 8 * slab + 2 * gn_align((size_t)rows * sizeof(float)) +
            gn_align((size_t)BWD_NWG * L.total() * sizeof(float)) + gn_align((size_t)L.total() * sizeof(float)) +
-           (H == 64 ? gn_pers64_ctl_bytes() : 0);
+           gn_pers64_ctl_bytes();
 }
 
 extern "C" size_t gnode_backward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H) {
@@ -1317,8 +1318,22 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         GN_LAUNCH_CHECK();
         const size_t fl = std::max((size_t)2 * H * H + (size_t)4 * rpw * H, (size_t)rpw * (4 * H + 12));
         const int grid = (int)std::min<long>(BWD_NWG, std::max<long>(1, (rows + rpw - 1) / rpw));
+        // batches that fit one resident grid: every interval in ONE persistent launch (gnode_persg.hip)
+        PersgPlan gp;
+        const bool gpersist = !(flags & GNODE_FWD_PER_STEP) && gn_persg_plan(g, rows, H, n_steps, &gp);
+        if (gpersist) {
+            int slot_prev[128];
+            slot_prev[0] = -1;
+            for (int j = 1; j <= G - 1; ++j) slot_prev[j] = slot_of(j - 1);
+            const bool sampled = gn_prof_begin(2, st);
+            if (int e = gn_launch_persg_bwd(g, gp, rows, H, G, ZIb[0], ZIb[1], Qb[0], Qb[1], ZS, sol, beta, gamma, a, part, gS, gI, gR, p,
+                                            dt_host, slot_prev, ws + backward_fixed_bytes(rows, H) - gn_pers64_ctl_bytes(), st))
+                return e;
+            if (sampled) gn_prof_end(2, st);
+            slots_used = std::max(slots_used, gp.wgs);
+        } else
         slots_used = std::max(slots_used, grid);
-        for (int i = G - 1; i >= 1; --i) {
+        for (int i = gpersist ? 0 : G - 1; i >= 1; --i) {
             const int cur = (G - 1 - i) & 1;
             const float *HubP0 = nullptr, *HubP1 = nullptr;        // segment partials; the interval kernel adds them up itself
             if (int e = gn_hub_segments2(g, rows / g->n, H, ZIb[cur], Qb[cur], hub_scratch, &HubP0, &HubP1, st)) return e;

@@ -32,7 +32,11 @@ struct gnode_graph_s {
     int32_t* perssegptr[3];
     int32_t* perssegitem[3];
     int32_t perslds[3];
-    int32_t persitems[3];   // most segment sums any one lane group was given (rounds of 32-row gathers the step waits for)
+    int32_t persitems[3];
+    // small hidden sizes (gnode_persg.hip), 128 / 64 / 32 rows per workgroup: lane-group slot -> node (-1 padding), hub rows dealt
+    // round-robin; the most neighbour ids of ordinary rows and the most hub segments one workgroup has to stage in LDS
+    int32_t* pgmap[3];
+    int32_t pgids[3], pgsegs[3];   // most segment sums any one lane group was given (rounds of 32-row gathers the step waits for)
 };
 
 #define HUB_SEG 32           // a hub row's neighbour list is cut into segments of this many edges
@@ -42,6 +46,8 @@ struct gnode_graph_s {
 int gn_hub_build(gnode_graph_s* g, const int32_t* rowptr_host);
 int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host);     // the row maps above (gnode_pers64.hip)
 void gn_pers64_free(gnode_graph_s* g);
+int gn_persg_build(gnode_graph_s* g, const int32_t* rowptr_host);      // row maps above (gnode_persg.hip)
+void gn_persg_free(gnode_graph_s* g);
 void gn_hub_free(gnode_graph_s* g);
 // Hub sums of `ntables` (1 or 2) tables for a batch of B samples need this much of the CALLER's workspace (0 for a graph
 // without hub rows); gn_hub_gather carves its segment partials and hub sums from it: no allocation, no

@@ -14,6 +14,7 @@
 // they are wanted (the generic node-MLP inner product).
 #include "gnode_common.h"
 #include "gnode_gather.h"
+#include "gnode_generic.h"
 #include "gnode_h64.h"
 #include <algorithm>
 
@@ -121,51 +122,6 @@ extern "C" int gnode_profile_read(double* gather_ms, int64_t* gather_launches, d
     if (mlp_ms) *mlp_ms = ms[1];
     if (mlp_launches) *mlp_launches = cnt[1];
     return 0;
-}
-
-// --------------------------------------------------------------------------- device helpers
-__device__ __forceinline__ float gn_sigmoid(float x) {
-    // 1 / (1 + exp(-x)) with the hardware exp2/rcp (v_exp_f32, v_rcp_f32: 1 ulp each)
-    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-
-template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, LPR);
-    return v;
-}
-
-// Read-out head for one row held by an LPR-lane group (each lane 4 features):
-// Linear(4,1)(relu(Linear(H,4)(y)))  ode_nn_ngraph_sim.py:172-182, for S, I, R, then
-// the 3-way softmax :184-187.  Every lane of the group returns the same values.
-template <int LPR>
-__device__ __forceinline__ void readout_row(float4 yS, float4 yI, float4 yR, bool active, int sub, int H,
-                                            const float* __restrict__ w3, const float* __restrict__ b3,
-                                            const float* __restrict__ w2, const float* __restrict__ b2,
-                                            float& pS, float& pI, float& pR) {
-    float qS = b2[0], qI = b2[0], qR = b2[0];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float4 w = active ? ld4(w3 + (size_t)k * H + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float s = fmaf(w.x, yS.x, fmaf(w.y, yS.y, fmaf(w.z, yS.z, w.w * yS.w)));
-        float i = fmaf(w.x, yI.x, fmaf(w.y, yI.y, fmaf(w.z, yI.z, w.w * yI.w)));
-        float r = fmaf(w.x, yR.x, fmaf(w.y, yR.y, fmaf(w.z, yR.z, w.w * yR.w)));
-        s = group_sum<LPR>(s) + b3[k];
-        i = group_sum<LPR>(i) + b3[k];
-        r = group_sum<LPR>(r) + b3[k];
-        qS = fmaf(w2[k], fmaxf(s, 0.f), qS);
-        qI = fmaf(w2[k], fmaxf(i, 0.f), qI);
-        qR = fmaf(w2[k], fmaxf(r, 0.f), qR);
-    }
-    float m = fmaxf(qS, fmaxf(qI, qR));
-    float eS = __expf(qS - m), eI = __expf(qI - m), eR = __expf(qR - m);
-    float inv = __builtin_amdgcn_rcpf(eS + eI + eR);
-    pS = eS * inv; pI = eI * inv; pR = eR * inv;
 }
 
 // --------------------------------------------------------------------------- K0: encoder
@@ -300,25 +256,6 @@ __global__ __launch_bounds__(256) void k_gather(const int* __restrict__ rowptr, 
 // structure as k_step64 -- gather, Z_S from Y_S, update, read-out, next step's Z_I -- with the node
 // MLP as a lane-group mat-vec: the row's H values live 4 per lane, x_k is broadcast inside the group
 // by shuffle and multiplied with W^T (staged in LDS, [k][j]).
-template <int LPR>
-__device__ __forceinline__ float4 group_mlp(float4 x, const float* __restrict__ Wt, float4 bias4, int sub, bool active,
-                                            int H) {
-    float4 acc = bias4;
-    const float xv[4] = {x.x, x.y, x.z, x.w};
-    for (int kk = 0; 4 * kk < H; ++kk) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float xk = __shfl(xv[c], kk, LPR);
-            if (active) {
-                const float4 w = ld4(Wt + (size_t)(4 * kk + c) * H + 4 * sub);
-                acc.x = fmaf(xk, w.x, acc.x); acc.y = fmaf(xk, w.y, acc.y);
-                acc.z = fmaf(xk, w.z, acc.z); acc.w = fmaf(xk, w.w, acc.w);
-            }
-        }
-    }
-    return make_float4(gn_sigmoid(acc.x), gn_sigmoid(acc.y), gn_sigmoid(acc.z), gn_sigmoid(acc.w));
-}
-
 template <int LPR>
 __global__ __launch_bounds__(256) void k_step_generic(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                       long rows, int H, float* Y,
@@ -523,6 +460,7 @@ static int launch_readout(const float* Y, long rows, int H, const gnode_params* 
 // device's CU count.  The only process-wide state besides the opt-in profiler: write-once per device, under a lock.
 #include <mutex>
 #include "gnode_pers64.h"
+#include "gnode_persg.h"
 static std::mutex g_dev_mu;
 static bool g_dev_done[64] = {};
 static int g_dev_cu[64] = {};
@@ -537,6 +475,7 @@ int gn_device_setup_once(int dev) {
     if (int e = gn_h64_set_attributes()) return e;
     if (int e = gn_pers64_set_attributes()) return e;
     if (int e = gn_pers_bwd64_set_attributes()) return e;
+    if (int e = gn_persg_set_attributes()) return e;
     if (int e = gn_h128_set_attributes()) return e;
     if (int e = gn_bwd_set_attributes()) return e;
     if (int e = gn_bwd_tiny_set_attributes()) return e;
@@ -606,9 +545,12 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
     for (int i = 0; i < 3; ++i) { g->persmap[i] = g->pershub[i] = g->perssegptr[i] = g->perssegitem[i] = nullptr; g->perslds[i] = 0; }
     int e_build = gn_hub_build(g, rowptr_host);
     if (!e_build) e_build = gn_pers64_build(g, rowptr_host);
+    for (int i = 0; i < 3; ++i) g->pgmap[i] = nullptr;
+    if (!e_build) e_build = gn_persg_build(g, rowptr_host);
     if (int e = e_build) {
         (void)hipFree(g->rowhdr);
         gn_pers64_free(g);
+        gn_persg_free(g);
         gn_hub_free(g);
         (void)hipFree(g->rowptr);
         (void)hipFree(g->col);
@@ -622,6 +564,7 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
 extern "C" int gnode_graph_destroy(gnode_graph_t g) {
     if (!g) return 0;
     gn_pers64_free(g);
+    gn_persg_free(g);
     gn_hub_free(g);
     (void)hipFree(g->rowptr);
     (void)hipFree(g->col);
@@ -674,6 +617,7 @@ extern "C" int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, co
 // its adjoint sweep 0.18 vs 0.35 ms), 1 = one workgroup per sample (tiny graphs in batches too large for one resident
 // grid), 0 = one launch per step.  The backward asks the same question (same arguments) to know what `sol` / `keep` hold.
 int gn_forward_kind(const gnode_graph_s* g, long rows, int H, int method, int n_steps, int n_out, bool with_sol, int flags, PersPlan* plan) {
+    if (method == 0 && H <= 32 && n_steps >= 1 && !(flags & GNODE_FWD_PER_STEP) && gn_persg_plan(g, rows, H, n_steps, nullptr)) return 3;
     if (!(H == 64 && method == 0) || n_steps < 1) return 0;
     PersPlan pl;
     if (!(flags & GNODE_FWD_PER_STEP) && gn_pers64_plan(g, rows / g->n, n_steps, &pl)) { if (plan) *plan = pl; return 2; }
@@ -689,7 +633,7 @@ static size_t forward_fixed_bytes(int64_t rows, int32_t H, int32_t method) {
     //   width read it instead of branching per neighbour)
     // + the control block of the persistent one-launch path (gnode_pers64.hip): tickets, barrier flags, give-up word
     return nslab * slab + 512 + 2 * gn_align((size_t)rows * sizeof(float)) + gn_align((size_t)rows * 4 * sizeof(float)) +
-           (H == 64 ? gn_pers64_ctl_bytes() : 0);
+           gn_pers64_ctl_bytes();
 }
 static char* forward_ctl_ptr(void* workspace, int64_t rows, int32_t H, int32_t method) {
     return (char*)workspace + forward_fixed_bytes(rows, H, method) - gn_pers64_ctl_bytes();
@@ -795,6 +739,25 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
                                      gamma, dt_host, slots, n_steps, p, S, I, R, sol, keep, forward_ctl_ptr(workspace, rows, H, method), st))
             return e;
         if (sampled) prof_mark(0, st);
+        return 0;
+    }
+
+    if (fkind == 3) {
+        // small hidden sizes, batches that fit one resident grid: ONE persistent launch (gnode_persg.hip)
+        PersgPlan gp;
+        gn_persg_plan(g, rows, H, n_steps, &gp);
+        int slots[128];
+        for (int k = 0; k < n_steps; ++k) slots[k] = out_slot(k + 1);
+        const bool sampled = prof_begin(0, st);
+        if (int e = gn_launch_persg(g, gp, rows, H, Y, zi_cur, zi_nxt, beta, gamma, dt_host, slots, n_steps, p, S, I, R, sol,
+                                    forward_ctl_ptr(workspace, rows, H, method), st))
+            return e;
+        if (sampled) prof_mark(0, st);
+        if (sol) {
+            const size_t slab4 = slab / 4;
+            hipLaunchKernelGGL(k_fill_bg, dim3((unsigned)std::min<size_t>((slab4 + 255) / 256, 2048)), dim3(256), 0, st, sol, slab4, G);
+            GN_LAUNCH_CHECK();
+        }
         return 0;
     }
 
@@ -911,7 +874,7 @@ extern "C" int gnode_forward_phase_ticks(int64_t rows, int32_t H, int32_t method
 extern "C" int gnode_forward_status(int64_t rows, int32_t H, int32_t method, const void* workspace, void* stream, int32_t* code_host) {
     GN_CHECK_ARG(workspace && code_host && rows > 0, "gnode_forward_status: null pointer");
     *code_host = 0;
-    if (H != 64) return 0;
+    if (H != 64 && H > 32) return 0;
     unsigned err[2] = {0, 0};
     const PersCtl* ctl = (const PersCtl*)forward_ctl_ptr(const_cast<void*>(workspace), rows, H, method);
     GN_HIP(hipMemcpyAsync(err, ctl->error, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -1,0 +1,536 @@
+// Persistent one-launch integration and adjoint sweep for the SMALL hidden sizes (H = 8, 16, 32: lane groups of H/4 lanes per
+// row; the multi-graph launcher trains with hidden 8 on a concatenated batch of graphs, monitorer-ngraphs.py:10,20,22).
+//
+// Where it sits: the per-step forms (k_step_generic / k_bwd_fused_generic, one launch per Euler step / adjoint interval) are
+// launch-latency bound on such batches -- 22k rows x 32-byte rows is 0.7 MB of state, 14.9 / 27.8 us per step / interval
+// measured -- exactly where H = 64 stood before gnode_pers64.hip.  Same cure, simpler shape:
+//
+//   * ONE launch, one workgroup per CU (dynamic LDS > half of the CU's 160 KB), a workgroup owns G = 256 / LPR rows of one sample
+//     (128 at H = 8; the graph's row map deals hub rows round-robin, the others in natural order) and keeps their state in REGISTERS for every step / interval;
+//   * only the gather tables travel: Z_I (forward), Z_I and q (adjoint), double-buffered; the hand-off between steps is the
+//     measured form of MI355X_MICROARCH.md's table for groups that span XCDs -- every storing wave `s_waitcnt vmcnt(0)`,
+//     workgroup barrier, ONE lane publishes the workgroup's epoch flag; the consumers' wave 0 polls all flags, barrier, every
+//     table load `sc1` (pers_wait / pers_ld / pers_st of gnode_pers64_dev.h);
+//   * a row's neighbour ids never change: they are staged ONCE in LDS as table byte offsets, so a step's gather is LDS id ->
+//     row load (one round trip), not row extent -> column ids -> rows;
+//   * hub rows (longer than GN_HUB_T): their <= 32-edge segments are dealt to the workgroup's lane groups, partial sums go
+//     through LDS and the owner adds them in segment order -- the same segments, the same ascending sums, the same
+//     segment-order total as k_hub_seg + the per-step consumers, so the forward's bits agree with the per-step path;
+//   * adjoint: the interval's Z(y_{i-1}), q, the head's VJP and a += dt g_Y as in k_bwd_fused_generic; gW = sum dpre^T y is
+//     accumulated in REGISTERS (a lane owns 4 rows of the H x H matrix: 4 H accumulators) behind the flag, where it overlaps
+//     the barrier's flight, and reduced once at the end of the sweep (the per-interval kernel walks its row tile with 64 of
+//     256 threads every interval).  Summation order differs from the per-interval path: gradients agree to rounding, not bits.
+//
+// Bounded spins: a workgroup that waits 2 s for an epoch writes a give-up code and the whole grid drains (pers_wait).
+#include "gnode_bwd.h"
+#include "gnode_common.h"
+#include "gnode_generic.h"
+#include "gnode_head64.h"
+#include "gnode_pers64_dev.h"
+#include "gnode_persg.h"
+#include <algorithm>
+#include <vector>
+
+static_assert(BWD_NWG >= 256, "a persistent workgroup writes partial-gradient slot blockIdx.x");
+
+struct PersgArgs {
+    const int* rowptr; const int* col; const int* hubidx; const int* hub_seg_ptr; const int* seg_lo; const int* seg_hi;
+    const int* rowmap;                   // [wps][G] lane-group slot -> node of the sample, -1 for padding (gnode_graph_s::pgmap)
+    int n, wgs, wps, segcap, idcap; unsigned rows;
+    const float* Y0;                     // forward: [3][rows][H] state at grid point 0
+    float* T0; float* T1;                // gather tables (forward: Z_I ping-pong)
+    float* Q0; float* Q1;                // adjoint: q ping-pong
+    const float* W; const float* bias; const float* beta; const float* gamma;
+    const float* w3; const float* b3; const float* w2; const float* b2;
+    float* S; float* I; float* R;        // forward outputs / adjoint: cotangents gS, gI, gR
+    float* sol;                          // trajectory [G][4][rows][H] (forward: written when non-null; adjoint: read)
+    const float* ZS0;                    // adjoint: Z_S(y_{G-1}) rows
+    float* a; float* part;               // adjoint state [3][rows][H], partial-gradient slots
+    PersCtl* ctl;
+    PersSched sched;                     // forward: dt[k], slot[k] of step k; adjoint: dt[i-1] at [i], slot of grid point i-1 at [i]
+};
+
+// LDS carve-up (floats): W^T [H*H] | W [H*H] | ids [idcap] | partials [2][segcap][H] | segment ids [segcap][32] |
+// segment list [segcap][2] | meta [8]
+struct PgLds {
+    float* Wt; float* Wl; unsigned* IDS; float* HP0; float* HP1; unsigned* HI; int* HS; int* meta;
+};
+template <int H>
+__device__ __forceinline__ PgLds pg_carve(float* lds, int idcap, int segcap) {
+    PgLds L;
+    L.Wt = lds; L.Wl = L.Wt + H * H; L.IDS = (unsigned*)(L.Wl + H * H);
+    L.HP0 = (float*)(L.IDS + idcap); L.HP1 = L.HP0 + (size_t)segcap * H;
+    L.HI = (unsigned*)(L.HP1 + (size_t)segcap * H); L.HS = (int*)(L.HI + (size_t)segcap * 32); L.meta = L.HS + 2 * segcap;
+    return L;
+}
+static size_t pg_lds_bytes(int H, int idcap, int segcap) {
+    const size_t need = sizeof(float) * ((size_t)2 * H * H + idcap + (size_t)2 * segcap * H + (size_t)segcap * 34 + 8);
+    // >= 84 KB: one workgroup per CU; the adjoint's final reduction borrows 64 KB behind the two weight copies
+    return std::max<size_t>(need, std::max<size_t>(84 * 1024, sizeof(float) * 2 * H * H + 64 * 1024 + 64));
+}
+
+// What a lane group knows about its row, staged once per launch.
+struct PgRow { bool inrow; unsigned r, off_b; int cnt, hub_n, hub_base; unsigned estart; };
+
+// Stage W (both orientations), the rows' neighbour ids and the hub segments' ids in LDS.  Returns the hub items of the workgroup.
+template <int LPR>
+__device__ __forceinline__ int pg_stage(const PersgArgs& a, const PgLds& L, PgRow& row) {
+    constexpr int GPW = 256 / LPR, H = 4 * LPR;
+    const int tid = threadIdx.x, sub = tid % LPR, grp = tid / LPR;
+    for (int idx = tid; idx < H * H; idx += 256) { const float v = a.W[idx]; L.Wl[idx] = v; L.Wt[(idx % H) * H + idx / H] = v; }
+    if (tid < 8) L.meta[tid] = 0;
+    __syncthreads();
+    // workgroup w serves sample w / wps; its lane groups own the nodes the graph's row map deals to local workgroup w % wps
+    const unsigned b = blockIdx.x / (unsigned)a.wps;
+    const int node = a.rowmap[(size_t)(blockIdx.x - b * (unsigned)a.wps) * GPW + grp];
+    row.inrow = node >= 0;
+    row.r = b * (unsigned)a.n + (unsigned)(row.inrow ? node : 0);
+    row.off_b = (row.r * (unsigned)H + 4u * sub) * 4u;
+    int start = 0, s0 = 0;
+    row.cnt = 0; row.hub_n = 0; row.hub_base = 0; row.estart = 0;
+    if (row.inrow) {
+        const int hub = a.hubidx ? a.hubidx[node] : -1;
+        if (hub < 0) { start = a.rowptr[node]; row.cnt = a.rowptr[node + 1] - start; }
+        else { s0 = a.hub_seg_ptr[hub]; row.hub_n = a.hub_seg_ptr[hub + 1] - s0; }
+    }
+    if (sub == 0) {
+        if (row.cnt) row.estart = (unsigned)atomicAdd(&L.meta[0], row.cnt);       // placement in LDS only: no effect on any sum
+        if (row.hub_n) row.hub_base = atomicAdd(&L.meta[1], row.hub_n);
+    }
+    row.estart = (unsigned)__shfl((int)row.estart, 0, LPR);
+    row.hub_base = __shfl(row.hub_base, 0, LPR);
+    for (int e = sub; e < row.cnt; e += LPR) L.IDS[row.estart + e] = (b * (unsigned)a.n + (unsigned)a.col[start + e]) * (unsigned)(H * 4);
+    for (int j = sub; j < row.hub_n; j += LPR) { L.HS[2 * (row.hub_base + j)] = s0 + j; L.HS[2 * (row.hub_base + j) + 1] = (int)(b * (unsigned)a.n); }
+    __syncthreads();
+    const int items = L.meta[1];
+    for (int it = grp; it < items; it += GPW) {
+        const int seg = L.HS[2 * it], lo = a.seg_lo[seg], hi = a.seg_hi[seg];
+        const unsigned bn = (unsigned)L.HS[2 * it + 1];
+        for (int e = sub; e < 32; e += LPR) L.HI[it * 32 + e] = (lo + e < hi) ? (bn + (unsigned)a.col[lo + e]) * (unsigned)(H * 4) : PS_OOB;
+    }
+    __syncthreads();
+    return items;
+}
+
+#define PG_ADD(A, V) A.x += V.x; A.y += V.y; A.z += V.z; A.w += V.w;
+
+// sum of up to `cnt` table rows whose byte offsets sit at ids[0 .. cnt), ascending, C in flight (slots past the end: PS_OOB,
+// answered with 0 by the buffer load's range check without a memory access)
+template <int C>
+__device__ __forceinline__ void pg_sum1(float4& acc, rsrc_t tab, const unsigned* ids, int cnt, unsigned lane_b) {
+    for (int e0 = 0; e0 < cnt; e0 += C) {
+        float4 v[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) v[k] = pers_ld<16>(tab, (e0 + k < cnt ? ids[e0 + k] : PS_OOB) + lane_b);
+#pragma unroll
+        for (int k = 0; k < C; ++k) { PG_ADD(acc, v[k]) }
+    }
+}
+template <int C>
+__device__ __forceinline__ void pg_sum2(float4& a0, float4& a1, rsrc_t t0, rsrc_t t1, const unsigned* ids, int cnt, unsigned lane_b) {
+    for (int e0 = 0; e0 < cnt; e0 += C) {
+        float4 u[C], v[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const unsigned o = (e0 + k < cnt ? ids[e0 + k] : PS_OOB) + lane_b;
+            u[k] = pers_ld<16>(t0, o); v[k] = pers_ld<16>(t1, o);
+        }
+#pragma unroll
+        for (int k = 0; k < C; ++k) { PG_ADD(a0, u[k]) PG_ADD(a1, v[k]) }
+    }
+}
+
+// wave 0 waits for `epoch`, everyone learns whether it gave up
+__device__ __forceinline__ bool pg_barrier(PersCtl* ctl, int wgs, unsigned epoch, int* meta) {
+    if (threadIdx.x < 64) {
+        if (!pers_wait(ctl->flags, wgs, epoch, ctl->error, threadIdx.x) && threadIdx.x == 0) meta[2] = 1;
+    }
+    __syncthreads();
+    return meta[2] == 0;
+}
+__device__ __forceinline__ void pg_publish(PersCtl* ctl, unsigned epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains, then the barrier, then ONE flag
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ctl->flags + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// --------------------------------------------------------------------------- forward: all Euler steps in one launch
+template <int LPR>
+__global__ __launch_bounds__(256) void k_persg(const PersgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int GPW = 256 / LPR, H = 4 * LPR, C = LPR <= 4 ? 16 : 8;
+    const PgLds L = pg_carve<H>(lds, a.idcap, a.segcap);
+    PgRow row;
+    const int items = pg_stage<LPR>(a, L, row);
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const unsigned tbytes = a.rows * (unsigned)(H * 4);
+    const rsrc_t tab[2] = {pers_rsrc(a.T0, tbytes), pers_rsrc(a.T1, tbytes)};
+    const unsigned lane_b = 16u * sub;
+    const size_t slab = (size_t)a.rows * H, off = (size_t)row.r * H + 4 * sub;
+    const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 yS = z0, yI = z0, yR = z0;
+    float nb = 0.f, gm = 0.f;
+    if (row.inrow) { yS = ld4(a.Y0 + off); yI = ld4(a.Y0 + slab + off); yR = ld4(a.Y0 + 2 * slab + off); nb = -a.beta[row.r]; gm = a.gamma[row.r]; }
+    const float4 bias4 = ld4(a.bias + 4 * sub);
+    float4 zmine = row.inrow ? ld4(a.T0 + off) : z0;      // the row's own Z_I(y_k): table 0 at step 0, carried in registers afterwards
+    const int n_steps = a.sched.n_steps;
+    for (int k = 0; k < n_steps; ++k) {
+        // Z_S(y_k) needs nothing from the other workgroups: it runs under the barrier's flight
+        const float4 zs = group_mlp<LPR>(yS, L.Wt, bias4, sub, true, H);
+        if (k > 0 && !pg_barrier(a.ctl, a.wgs, (unsigned)k, L.meta)) return;
+        const rsrc_t t = tab[k & 1];
+        float4 ai = z0;
+        if (items > 0) {                          // workgroup-uniform
+            for (int it = grp; it < items; it += GPW) {
+                float4 s = z0;
+                pg_sum1<16>(s, t, L.HI + it * 32, 32, lane_b);
+                st4(L.HP0 + (size_t)it * H + 4 * sub, s);
+            }
+            __syncthreads();
+            for (int j = 0; j < row.hub_n; ++j) { const float4 u = ld4(L.HP0 + (size_t)(row.hub_base + j) * H + 4 * sub); PG_ADD(ai, u) }
+        }
+        if (row.cnt) pg_sum1<C>(ai, t, L.IDS + row.estart, row.cnt, lane_b);
+        const float dt = a.sched.dt[k];
+        float4 dS, dI, dR;
+        dS.x = nb * (ai.x * zs.x); dS.y = nb * (ai.y * zs.y); dS.z = nb * (ai.z * zs.z); dS.w = nb * (ai.w * zs.w);
+        dR.x = gm * zmine.x; dR.y = gm * zmine.y; dR.z = gm * zmine.z; dR.w = gm * zmine.w;
+        dI.x = -dS.x - dR.x; dI.y = -dS.y - dR.y; dI.z = -dS.z - dR.z; dI.w = -dS.w - dR.w;
+        yS.x += dt * dS.x; yS.y += dt * dS.y; yS.z += dt * dS.z; yS.w += dt * dS.w;
+        yI.x += dt * dI.x; yI.y += dt * dI.y; yI.z += dt * dI.z; yI.w += dt * dI.w;
+        yR.x += dt * dR.x; yR.y += dt * dR.y; yR.z += dt * dR.z; yR.w += dt * dR.w;
+        if (k + 1 < n_steps) {
+            const float4 zn = group_mlp<LPR>(yI, L.Wt, bias4, sub, true, H);      // Z_I of the next step -> the other table
+            if (row.inrow) pers_st<16>(tab[(k + 1) & 1], row.off_b, zn);
+            pg_publish(a.ctl, (unsigned)k + 1u);
+            zmine = zn;
+        }
+        // behind the flag: the trajectory point and the read-out
+        if (a.sol && row.inrow) {
+            float* Yo = a.sol + (size_t)(k + 1) * 4 * slab;
+            st4(Yo + off, yS); st4(Yo + slab + off, yI); st4(Yo + 2 * slab + off, yR);
+        }
+        const int slot = a.sched.slot[k];
+        if (slot >= 0) {
+            float pS, pI, pR;
+            readout_row<LPR>(yS, yI, yR, true, sub, H, a.w3, a.b3, a.w2, a.b2, pS, pI, pR);
+            if (sub == 0 && row.inrow) { const size_t o = (size_t)slot * a.rows + row.r; a.S[o] = pS; a.I[o] = pI; a.R[o] = pR; }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------- adjoint: intervals G-1 .. 1 in one launch
+template <int LPR>
+__device__ __forceinline__ float4 pg_lin(float4 x, const float* __restrict__ M, int sub) {      // sum_k x_k M[k][4 sub ..]
+    constexpr int H = 4 * LPR;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int kk = 0; kk < LPR; ++kk) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float xk = __shfl(xv[c], kk, LPR);
+            const float4 w = ld4(M + (size_t)(4 * kk + c) * H + 4 * sub);
+            acc.x = fmaf(xk, w.x, acc.x); acc.y = fmaf(xk, w.y, acc.y); acc.z = fmaf(xk, w.z, acc.z); acc.w = fmaf(xk, w.w, acc.w);
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ float pg_sig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int GPW = 256 / LPR, H = 4 * LPR, C = LPR <= 4 ? 8 : 4;
+    const PgLds L = pg_carve<H>(lds, a.idcap, a.segcap);
+    PgRow row;
+    const int items = pg_stage<LPR>(a, L, row);
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const unsigned tbytes = a.rows * (unsigned)(H * 4);
+    const rsrc_t zt[2] = {pers_rsrc(a.T0, tbytes), pers_rsrc(a.T1, tbytes)};
+    const rsrc_t qt[2] = {pers_rsrc(a.Q0, tbytes), pers_rsrc(a.Q1, tbytes)};
+    const unsigned lane_b = 16u * sub;
+    const size_t slab = (size_t)a.rows * H, off = (size_t)row.r * H + 4 * sub;
+    const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int G = a.sched.n_steps + 1;
+    float4 aS = z0, aI = z0, aR = z0, zs0 = z0, zi0 = z0, yS = z0, yI = z0;
+    float bt = 0.f, gm = 0.f;
+    if (row.inrow) {
+        bt = a.beta[row.r]; gm = a.gamma[row.r];
+        aS = ld4(a.a + off); aI = ld4(a.a + slab + off); aR = ld4(a.a + 2 * slab + off);
+        zs0 = ld4(a.ZS0 + off); zi0 = ld4(a.T0 + off);
+        const float* Yl = a.sol + (size_t)(G - 1) * 4 * slab;
+        yS = ld4(Yl + off); yI = ld4(Yl + slab + off);
+    }
+    const float4 bias4 = ld4(a.bias + 4 * sub);
+    float4 w3v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w3v[k] = ld4(a.w3 + (size_t)k * H + 4 * sub);
+    HeadAcc hacc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hacc.dw3[k] = z0; hacc.db3[k] = 0.f; hacc.dw2[k] = 0.f; }
+    hacc.db2 = 0.f;
+    float accW[4][H];                    // gW rows 4 sub .. 4 sub + 3 (dt folded in), all H columns
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < H; ++k) accW[j][k] = 0.f;
+    float4 accb = z0;
+    for (int i = G - 1; i >= 1; --i) {
+        const int cur = (G - 1 - i) & 1;
+        const float dt = a.sched.dt[i];
+        const int slot = a.sched.slot[i];
+        // what the interval needs from the forward's trajectory travels under the barrier's flight
+        float4 y[3] = {z0, z0, z0};
+        float gout[3] = {0.f, 0.f, 0.f};
+        if (row.inrow) {
+            const float* Yp = a.sol + (size_t)(i - 1) * 4 * slab;
+            y[0] = ld4(Yp + off); y[1] = ld4(Yp + slab + off);
+            if (slot >= 0) {
+                y[2] = ld4(Yp + 2 * slab + off);
+                const size_t o = (size_t)slot * a.rows + row.r;
+                gout[0] = a.S[o]; gout[1] = a.I[o]; gout[2] = a.R[o];
+            }
+        }
+        if (i < G - 1 && !pg_barrier(a.ctl, a.wgs, (unsigned)(G - 1 - i), L.meta)) return;
+        float4 ai = z0, gq = z0;
+        if (items > 0) {
+            for (int it = grp; it < items; it += GPW) {
+                float4 s0 = z0, s1 = z0;
+                pg_sum2<16>(s0, s1, zt[cur], qt[cur], L.HI + it * 32, 32, lane_b);
+                st4(L.HP0 + (size_t)it * H + 4 * sub, s0); st4(L.HP1 + (size_t)it * H + 4 * sub, s1);
+            }
+            __syncthreads();
+            for (int j = 0; j < row.hub_n; ++j) {
+                const float4 u = ld4(L.HP0 + (size_t)(row.hub_base + j) * H + 4 * sub), v = ld4(L.HP1 + (size_t)(row.hub_base + j) * H + 4 * sub);
+                PG_ADD(ai, u) PG_ADD(gq, v)
+            }
+        }
+        if (row.cnt) pg_sum2<C>(ai, gq, zt[cur], qt[cur], L.IDS + row.estart, row.cnt, lane_b);
+        float4 dS, dI;
+#define PG_DPRE(c)                                                         \
+        {                                                                  \
+            const float v = bt * (aI.c - aS.c);                            \
+            dS.c = (v * ai.c) * (zs0.c * (1.0f - zs0.c));                  \
+            dI.c = (gq.c + gm * (aR.c - aI.c)) * (zi0.c * (1.0f - zi0.c)); \
+        }
+        PG_DPRE(x) PG_DPRE(y) PG_DPRE(z) PG_DPRE(w)
+#undef PG_DPRE
+        // g_Y = dpre W, a += dt g_Y
+        const float4 uS = pg_lin<LPR>(dS, L.Wl, sub), uI = pg_lin<LPR>(dI, L.Wl, sub);
+        aS.x += dt * uS.x; aS.y += dt * uS.y; aS.z += dt * uS.z; aS.w += dt * uS.w;
+        aI.x += dt * uI.x; aI.y += dt * uI.y; aI.z += dt * uI.z; aI.w += dt * uI.w;
+        // dL/dsol[i-1] through the head
+        if (slot >= 0) head_vjp64<LPR>(y, gout, w3v, a.b3, a.w2, a.b2, aS, aI, aR, hacc);
+        // Z(y_{i-1}) and q: the tables the next interval gathers
+        float4 zs = z0, zi = z0;
+        if (i > 1) {
+            zs = pg_lin<LPR>(y[0], L.Wt, sub); zi = pg_lin<LPR>(y[1], L.Wt, sub);
+            zs = make_float4(pg_sig(zs.x + bias4.x), pg_sig(zs.y + bias4.y), pg_sig(zs.z + bias4.z), pg_sig(zs.w + bias4.w));
+            zi = make_float4(pg_sig(zi.x + bias4.x), pg_sig(zi.y + bias4.y), pg_sig(zi.z + bias4.z), pg_sig(zi.w + bias4.w));
+            if (row.inrow) {
+                pers_st<16>(zt[cur ^ 1], row.off_b, zi);
+                pers_st<16>(qt[cur ^ 1], row.off_b, make_float4(bt * (aI.x - aS.x) * zs.x, bt * (aI.y - aS.y) * zs.y,
+                                                                bt * (aI.z - aS.z) * zs.z, bt * (aI.w - aS.w) * zs.w));
+            }
+            pg_publish(a.ctl, (unsigned)(G - i));
+        }
+        // behind the flag: gW += dt dpre^T y (S and I parts), gb += dt dpre
+        {
+            const float dv[2][4] = {{dt * dS.x, dt * dS.y, dt * dS.z, dt * dS.w}, {dt * dI.x, dt * dI.y, dt * dI.z, dt * dI.w}};
+            const float yv[2][4] = {{yS.x, yS.y, yS.z, yS.w}, {yI.x, yI.y, yI.z, yI.w}};
+#pragma unroll
+            for (int X = 0; X < 2; ++X)
+#pragma unroll
+                for (int kk = 0; kk < LPR; ++kk)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float yk = __shfl(yv[X][c], kk, LPR);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) accW[j][4 * kk + c] = fmaf(dv[X][j], yk, accW[j][4 * kk + c]);
+                    }
+            accb.x += dv[0][0] + dv[1][0]; accb.y += dv[0][1] + dv[1][1]; accb.z += dv[0][2] + dv[1][2]; accb.w += dv[0][3] + dv[1][3];
+        }
+        zs0 = zs; zi0 = zi; yS = y[0]; yI = y[1];
+    }
+    if (row.inrow) { st4(a.a + off, aS); st4(a.a + slab + off, aI); st4(a.a + 2 * slab + off, aR); }
+    // ---- one reduction per sweep: lane-group accumulators -> this workgroup's partial slot, fixed order
+    const PartLayout PL{H};
+    float* part = a.part + (size_t)blockIdx.x * PL.total();
+    float* red = L.Wl + H * H;                                  // 64 KB behind the weight copies (ids / partials are done with)
+    constexpr int NR = (16384 / (H * H)) < GPW ? (16384 / (H * H)) : GPW;      // lane groups per round
+    float tot[(H * H + 255) / 256];
+#pragma unroll
+    for (int m = 0; m < (H * H + 255) / 256; ++m) tot[m] = 0.f;
+    for (int g0 = 0; g0 < GPW; g0 += NR) {
+        __syncthreads();
+        if (grp >= g0 && grp < g0 + NR) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < H; ++k) red[(size_t)(grp - g0) * H * H + (4 * sub + j) * H + k] = accW[j][k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < (H * H + 255) / 256; ++m) {
+            const int e = threadIdx.x + 256 * m;
+            if (e < H * H) { float s = 0.f; for (int gi = 0; gi < NR; ++gi) s += red[(size_t)gi * H * H + e]; tot[m] += s; }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < (H * H + 255) / 256; ++m) { const int e = threadIdx.x + 256 * m; if (e < H * H) part[PL.oW() + e] += tot[m]; }
+    __syncthreads();
+    {
+        // gb, then the head's parameter gradients: [GPW][ne] rows, column sums in lane-group order
+        constexpr int ne = 5 * H + 12;                          // 4H + 9 head values, then the H gb values; rows 16-B aligned
+        float* mine = red + (size_t)grp * ne;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st4(mine + k * H + 4 * sub, hacc.dw3[k]);
+        if (sub == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mine[4 * H + k] = hacc.db3[k]; mine[4 * H + 4 + k] = hacc.dw2[k]; }
+            mine[4 * H + 8] = hacc.db2;
+        }
+        st4(mine + 4 * H + 12 + 4 * sub, accb);
+        __syncthreads();
+        for (int e = threadIdx.x; e < 5 * H + 12; e += 256) {
+            if (e >= 4 * H + 9 && e < 4 * H + 12) continue;
+            float s = 0.f;
+            for (int gi = 0; gi < GPW; ++gi) s += red[(size_t)gi * ne + e];
+            if (e < 4 * H + 9) part[PL.ow3() + e] += s;
+            else part[PL.ob() + (e - 4 * H - 12)] += s;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------- host: graph statistics, plan, launchers
+static int persg_vi(int H) { return H == 8 ? 0 : H == 16 ? 1 : H == 32 ? 2 : -1; }
+
+// Row maps for 128 / 64 / 32 rows per workgroup: hub rows (longest first) are dealt round-robin to the sample's workgroups --
+// real node numberings put the big nodes next to each other, and one workgroup owning them all would need their segments'
+// ids in its LDS and set every step's duration --, the other rows fill the workgroups in natural order.  Per variant: the
+// most neighbour ids of ordinary rows and the most hub segments one workgroup has to stage.
+int gn_persg_build(gnode_graph_s* g, const int32_t* rowptr_host) {
+    const int n = g->n;
+    for (int vi = 0; vi < 3; ++vi) { g->pgmap[vi] = nullptr; g->pgids[vi] = g->pgsegs[vi] = 0; }
+    if ((long)n > 256L * 128) return 0;                      // never fits one resident grid
+    std::vector<int> hubs, rest;
+    auto deg = [&](int i) { return rowptr_host[i + 1] - rowptr_host[i]; };
+    for (int i = 0; i < n; ++i) (g->n_hub > 0 && deg(i) > GN_HUB_T ? hubs : rest).push_back(i);
+    std::stable_sort(hubs.begin(), hubs.end(), [&](int x, int y) { return deg(x) > deg(y); });
+    for (int vi = 0; vi < 3; ++vi) {
+        const int gpw = 128 >> vi, wps = (n + gpw - 1) / gpw;
+        if (wps > 256) continue;
+        std::vector<std::vector<int>> own(wps);
+        for (size_t h = 0; h < hubs.size(); ++h) {             // snake order: 0 .. wps-1, wps-1 .. 0, ...
+            const size_t lap = h / wps, pos = h % wps;
+            own[(lap & 1) ? wps - 1 - pos : pos].push_back(hubs[h]);
+        }
+        bool ok = true;
+        for (int w = 0; w < wps; ++w) if ((int)own[w].size() > gpw) ok = false;
+        if (!ok) continue;
+        int w = 0;
+        for (int i : rest) {
+            while (w < wps && (int)own[w].size() >= gpw) ++w;
+            if (w >= wps) {                                   // (cannot happen: wps * gpw >= n) -- give the path up rather than trust it
+                ok = false;
+                break;
+            }
+            own[w].push_back(i);
+        }
+        if (!ok) continue;
+        std::vector<int32_t> map((size_t)wps * gpw, -1);
+        long best_i = 0, best_s = 0;
+        for (int ww = 0; ww < wps; ++ww) {
+            long ci = 0, cs = 0;
+            for (size_t k = 0; k < own[ww].size(); ++k) {
+                const int i = own[ww][k], d = deg(i);
+                map[(size_t)ww * gpw + k] = i;
+                if (g->n_hub > 0 && d > GN_HUB_T) cs += (d + HUB_SEG - 1) / HUB_SEG; else ci += d;
+            }
+            best_i = std::max(best_i, ci); best_s = std::max(best_s, cs);
+        }
+        g->pgids[vi] = (int32_t)std::min<long>(best_i, 1L << 30);
+        g->pgsegs[vi] = (int32_t)std::min<long>(best_s, 1L << 30);
+        GN_HIP(hipMalloc(&g->pgmap[vi], map.size() * sizeof(int32_t)));
+        GN_HIP(hipMemcpy(g->pgmap[vi], map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+void gn_persg_free(gnode_graph_s* g) {
+    for (int vi = 0; vi < 3; ++vi) { if (g->pgmap[vi]) (void)hipFree(g->pgmap[vi]); g->pgmap[vi] = nullptr; }
+}
+
+bool gn_persg_plan(const gnode_graph_s* g, long rows, int H, int n_steps, PersgPlan* p) {
+    const int vi = persg_vi(H);
+    if (vi < 0 || n_steps < 1 || n_steps > 127) return false;
+    if (!g->pgmap[vi]) return false;
+    const int gpw = 256 / (H / 4), wps = (g->n + gpw - 1) / gpw;
+    const long wgs = (rows / g->n) * wps;
+    if (wgs > std::min(g->num_cu, 256)) return false;              // one workgroup per CU, all resident; pers_wait sweeps 256 flags
+    if ((long)rows * H * 4 >= (1L << 31) - (1L << 17)) return false;    // 32-bit table offsets below PS_OOB
+    const int idcap = (g->pgids[vi] + 3) & ~3, segcap = std::max(4, (g->pgsegs[vi] + 3) & ~3);
+    const size_t need = sizeof(float) * ((size_t)2 * H * H + idcap + (size_t)2 * segcap * H + (size_t)segcap * 34 + 8);
+    if (need > 150 * 1024) return false;
+    if (p) { p->wgs = (int)wgs; p->wps = wps; p->idcap = idcap; p->segcap = segcap; p->lds = pg_lds_bytes(H, idcap, segcap); }
+    return true;
+}
+
+int gn_persg_set_attributes() {
+    const int mx = 160 * 1024;
+    GN_HIP(hipFuncSetAttribute((const void*)k_persg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    GN_HIP(hipFuncSetAttribute((const void*)k_persg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    GN_HIP(hipFuncSetAttribute((const void*)k_persg<8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    GN_HIP(hipFuncSetAttribute((const void*)k_persg_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    GN_HIP(hipFuncSetAttribute((const void*)k_persg_bwd<4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    GN_HIP(hipFuncSetAttribute((const void*)k_persg_bwd<8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    return 0;
+}
+
+static void persg_common(PersgArgs& a, const gnode_graph_s* g, const PersgPlan& pl, long rows, int H, const gnode_params* p, void* ctl) {
+    a.rowptr = g->rowptr; a.col = g->col; a.hubidx = g->n_hub > 0 ? g->hubidx : nullptr; a.hub_seg_ptr = g->hub_seg_ptr;
+    a.seg_lo = g->seg_lo; a.seg_hi = g->seg_hi;
+    a.rowmap = g->pgmap[persg_vi(H)];
+    a.n = g->n; a.wgs = pl.wgs; a.wps = pl.wps; a.segcap = pl.segcap; a.idcap = pl.idcap; a.rows = (unsigned)rows;
+    a.W = p->odefunc_linear_weight; a.bias = p->odefunc_linear_bias;
+    a.w3 = p->linear3_weight; a.b3 = p->linear3_bias; a.w2 = p->linearS2_weight; a.b2 = p->linearS2_bias;
+    a.ctl = (PersCtl*)ctl;
+    a.Y0 = nullptr; a.T0 = a.T1 = a.Q0 = a.Q1 = nullptr; a.S = a.I = a.R = nullptr; a.sol = nullptr; a.ZS0 = nullptr; a.a = a.part = nullptr;
+    a.beta = a.gamma = nullptr;
+}
+
+int gn_launch_persg(const gnode_graph_s* g, const PersgPlan& pl, long rows, int H, const float* Y0, float* Z0, float* Z1,
+                    const float* beta, const float* gamma, const float* dt_host, const int* slot_host, int n_steps,
+                    const gnode_params* p, float* S, float* I, float* R, float* sol, void* ctl, hipStream_t st) {
+    PersgArgs a;
+    persg_common(a, g, pl, rows, H, p, ctl);
+    a.Y0 = Y0; a.T0 = Z0; a.T1 = Z1; a.beta = beta; a.gamma = gamma; a.S = S; a.I = I; a.R = R; a.sol = sol;
+    a.sched.n_steps = n_steps;
+    for (int k = 0; k < n_steps; ++k) { a.sched.dt[k] = dt_host[k]; a.sched.slot[k] = (short)slot_host[k]; }
+    if (int e = gn_pers64_zero_ctl(ctl, st)) return e;             // flags and the give-up word: zeroed before EVERY launch
+    const dim3 grid((unsigned)pl.wgs);
+    if (H == 8) hipLaunchKernelGGL(k_persg<2>, grid, dim3(256), pl.lds, st, a);
+    else if (H == 16) hipLaunchKernelGGL(k_persg<4>, grid, dim3(256), pl.lds, st, a);
+    else hipLaunchKernelGGL(k_persg<8>, grid, dim3(256), pl.lds, st, a);
+    GN_LAUNCH_CHECK();
+    return 0;
+}
+
+int gn_launch_persg_bwd(const gnode_graph_s* g, const PersgPlan& pl, long rows, int H, int G, float* ZI0, float* ZI1, float* Q0, float* Q1,
+                        const float* ZS0, const float* sol, const float* beta, const float* gamma, float* a_state, float* part,
+                        const float* gS, const float* gI, const float* gR, const gnode_params* p, const float* dt_host,
+                        const int* slot_of_prev, void* ctl, hipStream_t st) {
+    PersgArgs a;
+    persg_common(a, g, pl, rows, H, p, ctl);
+    a.T0 = ZI0; a.T1 = ZI1; a.Q0 = Q0; a.Q1 = Q1; a.ZS0 = ZS0; a.sol = const_cast<float*>(sol); a.beta = beta; a.gamma = gamma;
+    a.a = a_state; a.part = part; a.S = const_cast<float*>(gS); a.I = const_cast<float*>(gI); a.R = const_cast<float*>(gR);
+    a.sched.n_steps = G - 1;
+    a.sched.dt[0] = 0.f; a.sched.slot[0] = -1;
+    for (int i = 1; i <= G - 1; ++i) { a.sched.dt[i] = dt_host[i - 1]; a.sched.slot[i] = (short)slot_of_prev[i]; }
+    if (int e = gn_pers64_zero_ctl(ctl, st)) return e;
+    const dim3 grid((unsigned)pl.wgs);
+    if (H == 8) hipLaunchKernelGGL(k_persg_bwd<2>, grid, dim3(256), pl.lds, st, a);
+    else if (H == 16) hipLaunchKernelGGL(k_persg_bwd<4>, grid, dim3(256), pl.lds, st, a);
+    else hipLaunchKernelGGL(k_persg_bwd<8>, grid, dim3(256), pl.lds, st, a);
+    GN_LAUNCH_CHECK();
+    return 0;
+}

@@ -11,7 +11,7 @@ CSRC = os.path.join(os.path.dirname(PKG), "csrc")
 ROOT = os.path.dirname(os.path.dirname(PKG))
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libgnode_hip.so")
-SOURCES = ["gnode_ode.hip", "gnode_h64.hip", "gnode_pers64.hip", "gnode_pers64_bwd.hip", "gnode_h128.hip", "gnode_bwd.hip", "gnode_bwd_tiny.hip", "gnode_hub.hip", "gnode_sir.hip", "gnode_dmp.hip", "gnode_meanfield.hip", "gnode_loss.hip"]
+SOURCES = ["gnode_ode.hip", "gnode_h64.hip", "gnode_pers64.hip", "gnode_pers64_bwd.hip", "gnode_persg.hip", "gnode_h128.hip", "gnode_bwd.hip", "gnode_bwd_tiny.hip", "gnode_hub.hip", "gnode_sir.hip", "gnode_dmp.hip", "gnode_meanfield.hip", "gnode_loss.hip"]
 # -ffp-contract=off: the SIR update must round like the reference's separate torch ops
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + INCLUDE, "-I" + CSRC]
 

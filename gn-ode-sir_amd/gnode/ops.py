@@ -142,7 +142,7 @@ def forward_path(graph: DeviceGraph, rows: int, H: int, n_steps: int, n_out: int
 def forward_status() -> int:
     """0, or the give-up code of the persistent launch behind the LAST `forward` call (synchronises the stream)."""
     rows, H, m, ws, path = forward.last_workspace
-    if path != 2:
+    if path not in (2, 3):
         return 0                                 # (the control block is only written by the persistent launch)
     code = C.c_int32(0)
     _lib.check(_lib.load().gnode_forward_status(rows, H, m, _lib.ptr(ws), _lib.stream_ptr(), C.byref(code)))

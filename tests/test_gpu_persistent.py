@@ -194,3 +194,75 @@ def test_persistent_training_step_under_graph_replay(n, m, dev):
         for k, v in model.named_parameters():
             if v.grad is not None:
                 assert torch.equal(v.grad, want[k]), (rep, k)
+
+
+# ---- small hidden sizes (csrc/gnode_persg.hip): the multi-graph launcher's H = 8 (monitorer-ngraphs.py:20), and 16 / 32
+def _setup_h(n, m, B, H, seed, dev, tail=0.0):
+    import torch
+    from gnode import synth
+    from gnode.graph import DeviceGraph
+    rp, ci = synth.heavy_tail_csr(n, m, tail, seed=seed) if tail else synth.er_csr(n, m, seed=seed)
+    g = DeviceGraph(rp, ci)
+    P = {k: torch.from_numpy(v).to(dev) for k, v in synth.linear_params(H, seed=seed + 1).items()}
+    x = torch.from_numpy(synth.samples(n, B, H, seed=seed + 2)).to(dev).reshape(B * n, 3 + H)
+    return g, P, x
+
+
+SMALL_H = [(22125, 250000, 1, 8, 0.0), (7066, 100736, 1, 8, 0.5), (1893, 13835, 3, 8, 0.8), (62, 159, 1, 8, 0.0), (300, 1500, 5, 8, 0.0),
+           (7066, 100736, 1, 16, 0.5), (4000, 30000, 2, 16, 0.0), (1893, 13835, 2, 32, 0.8), (5000, 40000, 1, 32, 0.0)]
+
+
+@pytest.mark.parametrize("n,m,B,H,tail", SMALL_H)
+def test_small_hidden_persistent_forward_bitwise(n, m, B, H, tail, dev):
+    """one persistent launch == one launch per Euler step, bit for bit (outputs and trajectory), hub rows included"""
+    import torch
+    from gnode import ops
+    g, P, x = _setup_h(n, m, B, H, 11, dev, tail)
+    maxTime, deltaT = 20, 0.5
+    dts = ops.step_sizes(ops.time_grid(maxTime, deltaT))
+    assert ops.forward_path(g, B * n, H, len(dts))[0] == 3
+    assert ops.forward_path(g, B * n, H, len(dts), persist=False)[0] == 0
+    for out_rows in (None, ops.subsample_rows(maxTime, deltaT)):
+        for want_sol in (False, True):
+            r0 = ops.forward(g, x, P, dts, "euler", out_rows, want_sol=want_sol, persist=False)
+            r1 = ops.forward(g, x, P, dts, "euler", out_rows, want_sol=want_sol, persist=True)
+            assert ops.forward_status() == 0
+            for a, b in zip(r0[:3], r1[:3]):
+                assert torch.equal(a, b), float((a - b).abs().max())
+            if want_sol:
+                assert torch.equal(r0[3], r1[3])
+    dts2 = np.asarray([0.5, 0.25, 1.0, 0.5, 0.125], dtype=np.float32)
+    r0 = ops.forward(g, x, P, dts2, "euler", np.asarray([0, 2, 5], dtype=np.int32), persist=False)
+    r1 = ops.forward(g, x, P, dts2, "euler", np.asarray([0, 2, 5], dtype=np.int32), persist=True)
+    assert all(torch.equal(a, b) for a, b in zip(r0[:3], r1[:3]))
+
+
+@pytest.mark.parametrize("n,m,B,H,tail", SMALL_H)
+def test_small_hidden_persistent_backward(n, m, B, H, tail, dev):
+    """the adjoint sweep as one persistent launch against one launch per interval: same per-row VJPs, parameter sums in a
+    different order -> 1e-5 of each gradient's scale; bitwise reproducible run to run"""
+    import torch
+    from gnode import ops
+    g, P, x = _setup_h(n, m, B, H, 13, dev, tail)
+    maxTime, deltaT = 20, 0.5
+    dts = ops.step_sizes(ops.time_grid(maxTime, deltaT))
+    rows_out = ops.subsample_rows(maxTime, deltaT)
+    gs = [torch.randn(len(rows_out), B * n, device=dev) for _ in range(3)]
+    S, I, R, sol = ops.forward(g, x, P, dts, "euler", rows_out, want_sol=True)
+    ref = ops.backward(g, x, P, dts, "euler", rows_out, sol, *gs, persist=False)
+    got = ops.backward(g, x, P, dts, "euler", rows_out, sol, *gs, persist=True)
+    again = ops.backward(g, x, P, dts, "euler", rows_out, sol, *gs, persist=True)
+    for k in ref:
+        scale = float((ref["linearS2.weight"] if k == "linearS2.bias" else ref[k]).abs().max()) + 1e-30
+        assert torch.equal(got[k], again[k]), k
+        err = float((got[k] - ref[k]).abs().max()) / scale
+        assert err <= 1e-5, (k, err)
+    # every grid point emitted (head VJP in every interval) and unequal steps
+    dts2 = np.asarray([0.5, 0.25, 1.0, 0.5, 0.125], dtype=np.float32)
+    gs2 = [torch.randn(6, B * n, device=dev) for _ in range(3)]
+    S, I, R, sol = ops.forward(g, x, P, dts2, "euler", None, want_sol=True)
+    ref = ops.backward(g, x, P, dts2, "euler", None, sol, *gs2, persist=False)
+    got = ops.backward(g, x, P, dts2, "euler", None, sol, *gs2, persist=True)
+    for k in ref:
+        scale = float((ref["linearS2.weight"] if k == "linearS2.bias" else ref[k]).abs().max()) + 1e-30
+        assert float((got[k] - ref[k]).abs().max()) / scale <= 1e-5, k
