@@ -431,19 +431,45 @@ def bench_h8(lib, dev):
         (l1_loss_sum(S, I, R, y, 1) / (tot * (maxTime - 1) * 3)).backward()
         opt.step()
 
-    train(); train()
-    torch.cuda.synchronize()
-    lib.gnode_profile_enable(1)
-    ms = _ev_ms(train, 10, warm=0)
-    f_ms, f_n = prof_read(lib, 0)
-    b_ms, b_n = prof_read(lib, 2)
-    lib.gnode_profile_enable(0)
+    def measure():
+        train(); train()
+        torch.cuda.synchronize()
+        lib.gnode_profile_enable(1)
+        ms = _ev_ms(train, 10, warm=0)
+        f_ms, f_n = prof_read(lib, 0)
+        b_ms, b_n = prof_read(lib, 2)
+        lib.gnode_profile_enable(0)
+        return ms, f_ms / max(f_n, 1) * 1e3, b_ms / max(b_n, 1) * 1e3
+
     sb = step_bytes(tot, nnz, H, False)
-    out["train batch of 8 graphs (62..7066 nodes)"] = {
-        "sum_nodes": tot, "nnz": nnz, "H": H, "euler_steps": n_steps, "train_step_ms": ms,
-        "fwd_step_kernel_avg_us (k_step_generic)": f_ms / max(f_n, 1) * 1e3, "bwd_interval_kernel_avg_us (k_bwd_fused_generic)": b_ms / max(b_n, 1) * 1e3,
-        "fwd_algorithmic_frac_of_hbm_peak": (sb["algorithmic"] / (f_ms / f_n * 1e-3) / 1e9 / HBM_PEAK_GBS) if f_n else None,
-        "limiter": "launch latency: 23k rows x 32-byte rows is 2.6 MB of state per step"}
+    g_batch = model.odefunc.graph_for(x[:, 3 + 2])
+    path = ops.forward_path(g_batch, tot, H, n_steps, len(rows), want_sol=True)[0]
+    ms, f_us, b_us = measure()
+    leg = {"sum_nodes": tot, "nnz": nnz, "H": H, "euler_steps": n_steps, "train_step_ms": ms,
+           "path": {0: "one launch per Euler step / interval", 3: "persistent one-launch (gnode_persg.hip)"}.get(path, str(path))}
+    if path == 3:
+        leg["fwd_launch_avg_us (all %d Euler steps, k_persg)" % n_steps] = f_us
+        leg["bwd_launch_avg_us (all %d intervals, k_persg_bwd)" % n_steps] = b_us
+        leg["fwd_us_per_euler_step"] = f_us / n_steps
+        leg["bwd_us_per_interval"] = b_us / n_steps
+        leg["fwd_algorithmic_frac_of_hbm_peak"] = sb["algorithmic"] * n_steps / (f_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        leg["limiter"] = "latency: per step one group barrier over 173 workgroups on 8 XCDs (~2-3 us of flag flight) + one gather round trip of 32-byte rows + the store drain; 0.7 MB of state per step"
+        # the same step behind one launch per Euler step / interval (GNODE_PERSIST=0's path)
+        prev = ops.PERSIST_DEFAULT
+        ops.PERSIST_DEFAULT = False
+        try:
+            ms0, f0, b0 = measure()
+        finally:
+            ops.PERSIST_DEFAULT = prev
+        leg["per_step_train_step_ms"] = ms0
+        leg["per_step_fwd_step_kernel_avg_us (k_step_generic)"] = f0
+        leg["per_step_bwd_interval_kernel_avg_us (k_bwd_fused_generic)"] = b0
+    else:
+        leg["fwd_step_kernel_avg_us (k_step_generic)"] = f_us
+        leg["bwd_interval_kernel_avg_us (k_bwd_fused_generic)"] = b_us
+        leg["fwd_algorithmic_frac_of_hbm_peak"] = sb["algorithmic"] / (f_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        leg["limiter"] = "launch latency: 23k rows x 32-byte rows is 0.7 MB of state per step"
+    out["train batch of 8 graphs (62..7066 nodes)"] = leg
     del y
     # ---- evaluation forward: 8 x 75k nodes
     xe = batch([5] * 8)

@@ -33,10 +33,11 @@ struct gnode_graph_s {
     int32_t* perssegitem[3];
     int32_t perslds[3];
     int32_t persitems[3];
-    // small hidden sizes (gnode_persg.hip), 128 / 64 / 32 rows per workgroup: lane-group slot -> node (-1 padding), hub rows dealt
-    // round-robin; the most neighbour ids of ordinary rows and the most hub segments one workgroup has to stage in LDS
-    int32_t* pgmap[3];
-    int32_t pgids[3], pgsegs[3];   // most segment sums any one lane group was given (rounds of 32-row gathers the step waits for)
+    // small hidden sizes (gnode_persg.hip; H = 8 / 16 / 32 x workgroups of 1 .. 4 waves): lane-group slot -> node (-1 padding),
+    // hub rows dealt round-robin, all variants in one allocation at pgoff[][] (-1: variant absent); per variant the most
+    // neighbour ids of ordinary rows and the most hub segments one workgroup has to stage in LDS
+    int32_t* pgmap;
+    int32_t pgoff[3][4], pgids[3][4], pgsegs[3][4];
 };
 
 #define HUB_SEG 32           // a hub row's neighbour list is cut into segments of this many edges

@@ -48,6 +48,31 @@ __device__ __forceinline__ void readout_row(float4 yS, float4 yI, float4 yR, boo
     pS = eS * inv; pI = eI * inv; pR = eR * inv;
 }
 
+// The same read-out with the head's weights already in registers (w3[k]: the lane's 4 columns of row k): same operations in
+// the same order as readout_row, so the same bits.
+template <int LPR>
+__device__ __forceinline__ void readout_row_regs(float4 yS, float4 yI, float4 yR, const float4 (&w3)[4], const float (&b3)[4],
+                                                 const float (&w2)[4], float b2, float& pS, float& pI, float& pR) {
+    float qS = b2, qI = b2, qR = b2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 w = w3[k];
+        float s = fmaf(w.x, yS.x, fmaf(w.y, yS.y, fmaf(w.z, yS.z, w.w * yS.w)));
+        float i = fmaf(w.x, yI.x, fmaf(w.y, yI.y, fmaf(w.z, yI.z, w.w * yI.w)));
+        float r = fmaf(w.x, yR.x, fmaf(w.y, yR.y, fmaf(w.z, yR.z, w.w * yR.w)));
+        s = group_sum<LPR>(s) + b3[k];
+        i = group_sum<LPR>(i) + b3[k];
+        r = group_sum<LPR>(r) + b3[k];
+        qS = fmaf(w2[k], fmaxf(s, 0.f), qS);
+        qI = fmaf(w2[k], fmaxf(i, 0.f), qI);
+        qR = fmaf(w2[k], fmaxf(r, 0.f), qR);
+    }
+    float m = fmaxf(qS, fmaxf(qI, qR));
+    float eS = __expf(qS - m), eI = __expf(qI - m), eR = __expf(qR - m);
+    float inv = __builtin_amdgcn_rcpf(eS + eI + eR);
+    pS = eS * inv; pI = eI * inv; pR = eR * inv;
+}
+
 // Node MLP of one row: sigmoid(W x + b).  x_k is broadcast inside the group by shuffle and multiplied with W^T (staged in LDS,
 // Wt[k][j] = W[j][k]); every lane of the wave must call it (shuffles), `active` guards the LDS reads.
 template <int LPR>

@@ -545,7 +545,7 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
     for (int i = 0; i < 3; ++i) { g->persmap[i] = g->pershub[i] = g->perssegptr[i] = g->perssegitem[i] = nullptr; g->perslds[i] = 0; }
     int e_build = gn_hub_build(g, rowptr_host);
     if (!e_build) e_build = gn_pers64_build(g, rowptr_host);
-    for (int i = 0; i < 3; ++i) g->pgmap[i] = nullptr;
+    g->pgmap = nullptr;
     if (!e_build) e_build = gn_persg_build(g, rowptr_host);
     if (int e = e_build) {
         (void)hipFree(g->rowhdr);

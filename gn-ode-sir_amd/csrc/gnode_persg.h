@@ -2,7 +2,7 @@
 #pragma once
 #include "gnode_common.h"
 
-struct PersgPlan { int wgs, wps, idcap, segcap; size_t lds; };
+struct PersgPlan { int wgs, wps, nw, map_off, idcap, segcap; size_t lds; };   // nw: waves per workgroup (64 / LPR rows each)
 
 // false: this (graph, rows, H, horizon) keeps the one-launch-per-step forms (more rows than one resident grid of one workgroup
 // per CU holds, a window of rows whose neighbour ids / hub segments do not fit a workgroup's LDS, other hidden sizes)

@@ -31,6 +31,12 @@
 #include <algorithm>
 #include <vector>
 
+#ifndef GN_PERSG_NB
+#define GN_PERSG_NB 5          // batches of 8 neighbour rows in flight per lane, forward
+#endif
+#ifndef GN_PERSG_BNB
+#define GN_PERSG_BNB 2         // ... per table, adjoint (two tables through one id list)
+#endif
 static_assert(BWD_NWG >= 256, "a persistent workgroup writes partial-gradient slot blockIdx.x");
 
 struct PersgArgs {
@@ -75,9 +81,10 @@ struct PgRow { bool inrow; unsigned r, off_b; int cnt, hub_n, hub_base; unsigned
 // Stage W (both orientations), the rows' neighbour ids and the hub segments' ids in LDS.  Returns the hub items of the workgroup.
 template <int LPR>
 __device__ __forceinline__ int pg_stage(const PersgArgs& a, const PgLds& L, PgRow& row) {
-    constexpr int GPW = 256 / LPR, H = 4 * LPR;
+    constexpr int H = 4 * LPR;
+    const int GPW = (int)blockDim.x / LPR;
     const int tid = threadIdx.x, sub = tid % LPR, grp = tid / LPR;
-    for (int idx = tid; idx < H * H; idx += 256) { const float v = a.W[idx]; L.Wl[idx] = v; L.Wt[(idx % H) * H + idx / H] = v; }
+    for (int idx = tid; idx < H * H; idx += (int)blockDim.x) { const float v = a.W[idx]; L.Wl[idx] = v; L.Wt[(idx % H) * H + idx / H] = v; }
     if (tid < 8) L.meta[tid] = 0;
     __syncthreads();
     // workgroup w serves sample w / wps; its lane groups own the nodes the graph's row map deals to local workgroup w % wps
@@ -114,30 +121,57 @@ __device__ __forceinline__ int pg_stage(const PersgArgs& a, const PgLds& L, PgRo
 
 #define PG_ADD(A, V) A.x += V.x; A.y += V.y; A.z += V.z; A.w += V.w;
 
-// sum of up to `cnt` table rows whose byte offsets sit at ids[0 .. cnt), ascending, C in flight (slots past the end: PS_OOB,
-// answered with 0 by the buffer load's range check without a memory access)
-template <int C>
-__device__ __forceinline__ void pg_sum1(float4& acc, rsrc_t tab, const unsigned* ids, int cnt, unsigned lane_b) {
-    for (int e0 = 0; e0 < cnt; e0 += C) {
-        float4 v[C];
+// Sum of the `cnt` table rows whose byte offsets sit at ids[0 .. cnt), ascending, up to 8 NB in flight.  Loads are issued in
+// batches of 8 as far as the LONGEST row of the wave needs (cmax, wave-uniform): a load instruction costs the CU's texture
+// unit 16 cycles whatever its lanes fetch, and with one wave per SIMD both the instruction count and the round trips are
+// exposed.  Slots past a row's end carry PS_OOB (answered with 0 by the buffer's range check, no memory access; adding +0
+// leaves the sum's bits alone).
+template <int NB>
+__device__ __forceinline__ void pg_sum1(float4& acc, rsrc_t tab, const unsigned* ids, int cnt, int cmax, unsigned lane_b) {
+    for (int e0 = 0; e0 < cmax; e0 += 8 * NB) {
+        float4 v[8 * NB];
+        const int nb = (cmax - e0 + 7) >> 3;
 #pragma unroll
-        for (int k = 0; k < C; ++k) v[k] = pers_ld<16>(tab, (e0 + k < cnt ? ids[e0 + k] : PS_OOB) + lane_b);
+        for (int j = 0; j < NB; ++j)
+            if (j < nb) {
 #pragma unroll
-        for (int k = 0; k < C; ++k) { PG_ADD(acc, v[k]) }
+                for (int k = 0; k < 8; ++k) { const int e = e0 + 8 * j + k; v[8 * j + k] = pers_ld<16>(tab, (e < cnt ? ids[e] : PS_OOB) + lane_b); }
+            }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (j < nb) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { PG_ADD(acc, v[8 * j + k]) }
+            }
     }
 }
-template <int C>
-__device__ __forceinline__ void pg_sum2(float4& a0, float4& a1, rsrc_t t0, rsrc_t t1, const unsigned* ids, int cnt, unsigned lane_b) {
-    for (int e0 = 0; e0 < cnt; e0 += C) {
-        float4 u[C], v[C];
+template <int NB>
+__device__ __forceinline__ void pg_sum2(float4& a0, float4& a1, rsrc_t t0, rsrc_t t1, const unsigned* ids, int cnt, int cmax, unsigned lane_b) {
+    for (int e0 = 0; e0 < cmax; e0 += 8 * NB) {
+        float4 u[8 * NB], v[8 * NB];
+        const int nb = (cmax - e0 + 7) >> 3;
 #pragma unroll
-        for (int k = 0; k < C; ++k) {
-            const unsigned o = (e0 + k < cnt ? ids[e0 + k] : PS_OOB) + lane_b;
-            u[k] = pers_ld<16>(t0, o); v[k] = pers_ld<16>(t1, o);
-        }
+        for (int j = 0; j < NB; ++j)
+            if (j < nb) {
 #pragma unroll
-        for (int k = 0; k < C; ++k) { PG_ADD(a0, u[k]) PG_ADD(a1, v[k]) }
+                for (int k = 0; k < 8; ++k) {
+                    const int e = e0 + 8 * j + k;
+                    const unsigned o = (e < cnt ? ids[e] : PS_OOB) + lane_b;
+                    u[8 * j + k] = pers_ld<16>(t0, o); v[8 * j + k] = pers_ld<16>(t1, o);
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (j < nb) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { PG_ADD(a0, u[8 * j + k]) PG_ADD(a1, v[8 * j + k]) }
+            }
     }
+}
+__device__ __forceinline__ int pg_wave_max(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 // wave 0 waits for `epoch`, everyone learns whether it gave up
@@ -158,10 +192,12 @@ __device__ __forceinline__ void pg_publish(PersCtl* ctl, unsigned epoch) {
 template <int LPR>
 __global__ __launch_bounds__(256) void k_persg(const PersgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int GPW = 256 / LPR, H = 4 * LPR, C = LPR <= 4 ? 16 : 8;
+    constexpr int H = 4 * LPR;
+    const int GPW = (int)blockDim.x / LPR;                  // 1 .. 4 waves per workgroup (the plan's choice)
     const PgLds L = pg_carve<H>(lds, a.idcap, a.segcap);
     PgRow row;
     const int items = pg_stage<LPR>(a, L, row);
+    const int cmax = pg_wave_max(row.cnt);            // the wave's longest ordinary row
     const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     const unsigned tbytes = a.rows * (unsigned)(H * 4);
     const rsrc_t tab[2] = {pers_rsrc(a.T0, tbytes), pers_rsrc(a.T1, tbytes)};
@@ -172,24 +208,37 @@ __global__ __launch_bounds__(256) void k_persg(const PersgArgs a) {
     float nb = 0.f, gm = 0.f;
     if (row.inrow) { yS = ld4(a.Y0 + off); yI = ld4(a.Y0 + slab + off); yR = ld4(a.Y0 + 2 * slab + off); nb = -a.beta[row.r]; gm = a.gamma[row.r]; }
     const float4 bias4 = ld4(a.bias + 4 * sub);
+    // the read-out head's weights live in registers: with one wave per SIMD a global load inside the step is exposed latency
+    float4 w3r[4];
+    float b3r[4], w2r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { w3r[k] = ld4(a.w3 + (size_t)k * H + 4 * sub); b3r[k] = a.b3[k]; w2r[k] = a.w2[k]; }
+    const float b2r = a.b2[0];
     float4 zmine = row.inrow ? ld4(a.T0 + off) : z0;      // the row's own Z_I(y_k): table 0 at step 0, carried in registers afterwards
     const int n_steps = a.sched.n_steps;
+#ifdef GN_PERS_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int k = 0; k < n_steps; ++k) {
         // Z_S(y_k) needs nothing from the other workgroups: it runs under the barrier's flight
         const float4 zs = group_mlp<LPR>(yS, L.Wt, bias4, sub, true, H);
+        PS_STAMP(0)
         if (k > 0 && !pg_barrier(a.ctl, a.wgs, (unsigned)k, L.meta)) return;
+        PS_STAMP(1)
         const rsrc_t t = tab[k & 1];
         float4 ai = z0;
         if (items > 0) {                          // workgroup-uniform
             for (int it = grp; it < items; it += GPW) {
                 float4 s = z0;
-                pg_sum1<16>(s, t, L.HI + it * 32, 32, lane_b);
+                pg_sum1<4>(s, t, L.HI + it * 32, 32, 32, lane_b);
                 st4(L.HP0 + (size_t)it * H + 4 * sub, s);
             }
             __syncthreads();
             for (int j = 0; j < row.hub_n; ++j) { const float4 u = ld4(L.HP0 + (size_t)(row.hub_base + j) * H + 4 * sub); PG_ADD(ai, u) }
         }
-        if (row.cnt) pg_sum1<C>(ai, t, L.IDS + row.estart, row.cnt, lane_b);
+        PS_STAMP(2)
+        pg_sum1<GN_PERSG_NB>(ai, t, L.IDS + row.estart, row.cnt, cmax, lane_b);
+        PS_STAMP(3)
         const float dt = a.sched.dt[k];
         float4 dS, dI, dR;
         dS.x = nb * (ai.x * zs.x); dS.y = nb * (ai.y * zs.y); dS.z = nb * (ai.z * zs.z); dS.w = nb * (ai.w * zs.w);
@@ -201,7 +250,9 @@ __global__ __launch_bounds__(256) void k_persg(const PersgArgs a) {
         if (k + 1 < n_steps) {
             const float4 zn = group_mlp<LPR>(yI, L.Wt, bias4, sub, true, H);      // Z_I of the next step -> the other table
             if (row.inrow) pers_st<16>(tab[(k + 1) & 1], row.off_b, zn);
+            PS_STAMP(4)
             pg_publish(a.ctl, (unsigned)k + 1u);
+            PS_STAMP(5)
             zmine = zn;
         }
         // behind the flag: the trajectory point and the read-out
@@ -212,10 +263,14 @@ __global__ __launch_bounds__(256) void k_persg(const PersgArgs a) {
         const int slot = a.sched.slot[k];
         if (slot >= 0) {
             float pS, pI, pR;
-            readout_row<LPR>(yS, yI, yR, true, sub, H, a.w3, a.b3, a.w2, a.b2, pS, pI, pR);
+            readout_row_regs<LPR>(yS, yI, yR, w3r, b3r, w2r, b2r, pS, pI, pR);
             if (sub == 0 && row.inrow) { const size_t o = (size_t)slot * a.rows + row.r; a.S[o] = pS; a.I[o] = pI; a.R[o] = pR; }
         }
+        PS_STAMP(6)
     }
+#ifdef GN_PERS_PROF
+    if (threadIdx.x == 0 && blockIdx.x == 0) for (int i = 0; i < 8; ++i) a.ctl->prof[i] = prof[i];
+#endif
 }
 
 // --------------------------------------------------------------------------- adjoint: intervals G-1 .. 1 in one launch
@@ -240,10 +295,12 @@ __device__ __forceinline__ float pg_sig(float x) { return __builtin_amdgcn_rcpf(
 template <int LPR>
 __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int GPW = 256 / LPR, H = 4 * LPR, C = LPR <= 4 ? 8 : 4;
+    constexpr int H = 4 * LPR;
+    const int GPW = (int)blockDim.x / LPR;                  // 1 .. 4 waves per workgroup (the plan's choice)
     const PgLds L = pg_carve<H>(lds, a.idcap, a.segcap);
     PgRow row;
     const int items = pg_stage<LPR>(a, L, row);
+    const int cmax = pg_wave_max(row.cnt);            // the wave's longest ordinary row
     const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     const unsigned tbytes = a.rows * (unsigned)(H * 4);
     const rsrc_t zt[2] = {pers_rsrc(a.T0, tbytes), pers_rsrc(a.T1, tbytes)};
@@ -296,7 +353,7 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
         if (items > 0) {
             for (int it = grp; it < items; it += GPW) {
                 float4 s0 = z0, s1 = z0;
-                pg_sum2<16>(s0, s1, zt[cur], qt[cur], L.HI + it * 32, 32, lane_b);
+                pg_sum2<2>(s0, s1, zt[cur], qt[cur], L.HI + it * 32, 32, 32, lane_b);
                 st4(L.HP0 + (size_t)it * H + 4 * sub, s0); st4(L.HP1 + (size_t)it * H + 4 * sub, s1);
             }
             __syncthreads();
@@ -305,7 +362,7 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
                 PG_ADD(ai, u) PG_ADD(gq, v)
             }
         }
-        if (row.cnt) pg_sum2<C>(ai, gq, zt[cur], qt[cur], L.IDS + row.estart, row.cnt, lane_b);
+        pg_sum2<GN_PERSG_BNB>(ai, gq, zt[cur], qt[cur], L.IDS + row.estart, row.cnt, cmax, lane_b);
         float4 dS, dI;
 #define PG_DPRE(c)                                                         \
         {                                                                  \
@@ -357,10 +414,7 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
     const PartLayout PL{H};
     float* part = a.part + (size_t)blockIdx.x * PL.total();
     float* red = L.Wl + H * H;                                  // 64 KB behind the weight copies (ids / partials are done with)
-    constexpr int NR = (16384 / (H * H)) < GPW ? (16384 / (H * H)) : GPW;      // lane groups per round
-    float tot[(H * H + 255) / 256];
-#pragma unroll
-    for (int m = 0; m < (H * H + 255) / 256; ++m) tot[m] = 0.f;
+    const int NR = min(16384 / (H * H), GPW);                   // lane groups per round
     for (int g0 = 0; g0 < GPW; g0 += NR) {
         __syncthreads();
         if (grp >= g0 && grp < g0 + NR) {
@@ -370,14 +424,13 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
                 for (int k = 0; k < H; ++k) red[(size_t)(grp - g0) * H * H + (4 * sub + j) * H + k] = accW[j][k];
         }
         __syncthreads();
-#pragma unroll
-        for (int m = 0; m < (H * H + 255) / 256; ++m) {
-            const int e = threadIdx.x + 256 * m;
-            if (e < H * H) { float s = 0.f; for (int gi = 0; gi < NR; ++gi) s += red[(size_t)gi * H * H + e]; tot[m] += s; }
+        const int ng = min(NR, GPW - g0);
+        for (int e = threadIdx.x; e < H * H; e += (int)blockDim.x) {
+            float s = 0.f;
+            for (int gi = 0; gi < ng; ++gi) s += red[(size_t)gi * H * H + e];
+            part[PL.oW() + e] += s;
         }
     }
-#pragma unroll
-    for (int m = 0; m < (H * H + 255) / 256; ++m) { const int e = threadIdx.x + 256 * m; if (e < H * H) part[PL.oW() + e] += tot[m]; }
     __syncthreads();
     {
         // gb, then the head's parameter gradients: [GPW][ne] rows, column sums in lane-group order
@@ -392,7 +445,7 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
         }
         st4(mine + 4 * H + 12 + 4 * sub, accb);
         __syncthreads();
-        for (int e = threadIdx.x; e < 5 * H + 12; e += 256) {
+        for (int e = threadIdx.x; e < 5 * H + 12; e += (int)blockDim.x) {
             if (e >= 4 * H + 9 && e < 4 * H + 12) continue;
             float s = 0.f;
             for (int gi = 0; gi < GPW; ++gi) s += red[(size_t)gi * ne + e];
@@ -405,74 +458,79 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
 // --------------------------------------------------------------------------- host: graph statistics, plan, launchers
 static int persg_vi(int H) { return H == 8 ? 0 : H == 16 ? 1 : H == 32 ? 2 : -1; }
 
-// Row maps for 128 / 64 / 32 rows per workgroup: hub rows (longest first) are dealt round-robin to the sample's workgroups --
-// real node numberings put the big nodes next to each other, and one workgroup owning them all would need their segments'
-// ids in its LDS and set every step's duration --, the other rows fill the workgroups in natural order.  Per variant: the
-// most neighbour ids of ordinary rows and the most hub segments one workgroup has to stage.
+// Row maps for workgroups of 1 .. 4 waves (a wave holds 64 / LPR rows: 32 at H = 8): rows are dealt longest first, round-robin,
+// to the sample's workgroups -- real node numberings put the big nodes next to each other, and one workgroup owning them all
+// would need their segments' ids in its LDS and set every step's duration.  Per variant: the most neighbour ids of ordinary rows and the most hub segments one workgroup
+// has to stage.  All maps of a graph live in ONE device allocation.
 int gn_persg_build(gnode_graph_s* g, const int32_t* rowptr_host) {
     const int n = g->n;
-    for (int vi = 0; vi < 3; ++vi) { g->pgmap[vi] = nullptr; g->pgids[vi] = g->pgsegs[vi] = 0; }
+    g->pgmap = nullptr;
+    for (int vi = 0; vi < 3; ++vi) for (int nw = 0; nw < 4; ++nw) { g->pgoff[vi][nw] = -1; g->pgids[vi][nw] = g->pgsegs[vi][nw] = 0; }
     if ((long)n > 256L * 128) return 0;                      // never fits one resident grid
-    std::vector<int> hubs, rest;
+    // every row, longest first (hub rows lead), dealt in snake order: each workgroup gets its share of the long rows AND of the
+    // neighbour ids -- what a step waits for is the busiest workgroup's gather
+    std::vector<int> order(n);
     auto deg = [&](int i) { return rowptr_host[i + 1] - rowptr_host[i]; };
-    for (int i = 0; i < n; ++i) (g->n_hub > 0 && deg(i) > GN_HUB_T ? hubs : rest).push_back(i);
-    std::stable_sort(hubs.begin(), hubs.end(), [&](int x, int y) { return deg(x) > deg(y); });
-    for (int vi = 0; vi < 3; ++vi) {
-        const int gpw = 128 >> vi, wps = (n + gpw - 1) / gpw;
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return deg(x) > deg(y); });
+    std::vector<int32_t> all;
+    for (int vi = 0; vi < 3; ++vi)
+    for (int nw = 1; nw <= 4; ++nw) {
+        const int gpw = (32 >> vi) * nw, wps = (n + gpw - 1) / gpw;
         if (wps > 256) continue;
         std::vector<std::vector<int>> own(wps);
-        for (size_t h = 0; h < hubs.size(); ++h) {             // snake order: 0 .. wps-1, wps-1 .. 0, ...
+        for (size_t h = 0; h < order.size(); ++h) {            // snake order: 0 .. wps-1, wps-1 .. 0, ...
             const size_t lap = h / wps, pos = h % wps;
-            own[(lap & 1) ? wps - 1 - pos : pos].push_back(hubs[h]);
+            own[(lap & 1) ? wps - 1 - pos : pos].push_back(order[h]);
         }
         bool ok = true;
-        for (int w = 0; w < wps; ++w) if ((int)own[w].size() > gpw) ok = false;
+        for (int w = 0; w < wps; ++w) if ((int)own[w].size() > gpw) ok = false;     // (cannot happen: wps * gpw >= n)
         if (!ok) continue;
-        int w = 0;
-        for (int i : rest) {
-            while (w < wps && (int)own[w].size() >= gpw) ++w;
-            if (w >= wps) {                                   // (cannot happen: wps * gpw >= n) -- give the path up rather than trust it
-                ok = false;
-                break;
-            }
-            own[w].push_back(i);
-        }
-        if (!ok) continue;
-        std::vector<int32_t> map((size_t)wps * gpw, -1);
+        const size_t off = all.size();
+        all.resize(off + (size_t)wps * gpw, -1);
         long best_i = 0, best_s = 0;
         for (int ww = 0; ww < wps; ++ww) {
             long ci = 0, cs = 0;
             for (size_t k = 0; k < own[ww].size(); ++k) {
                 const int i = own[ww][k], d = deg(i);
-                map[(size_t)ww * gpw + k] = i;
+                all[off + (size_t)ww * gpw + k] = i;
                 if (g->n_hub > 0 && d > GN_HUB_T) cs += (d + HUB_SEG - 1) / HUB_SEG; else ci += d;
             }
             best_i = std::max(best_i, ci); best_s = std::max(best_s, cs);
         }
-        g->pgids[vi] = (int32_t)std::min<long>(best_i, 1L << 30);
-        g->pgsegs[vi] = (int32_t)std::min<long>(best_s, 1L << 30);
-        GN_HIP(hipMalloc(&g->pgmap[vi], map.size() * sizeof(int32_t)));
-        GN_HIP(hipMemcpy(g->pgmap[vi], map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        g->pgoff[vi][nw - 1] = (int32_t)off;
+        g->pgids[vi][nw - 1] = (int32_t)std::min<long>(best_i, 1L << 30);
+        g->pgsegs[vi][nw - 1] = (int32_t)std::min<long>(best_s, 1L << 30);
     }
+    if (all.empty()) return 0;
+    GN_HIP(hipMalloc(&g->pgmap, all.size() * sizeof(int32_t)));
+    GN_HIP(hipMemcpy(g->pgmap, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     return 0;
 }
 void gn_persg_free(gnode_graph_s* g) {
-    for (int vi = 0; vi < 3; ++vi) { if (g->pgmap[vi]) (void)hipFree(g->pgmap[vi]); g->pgmap[vi] = nullptr; }
+    if (g->pgmap) (void)hipFree(g->pgmap);
+    g->pgmap = nullptr;
 }
 
+// The fewest rows per workgroup (most CUs) that still leaves every workgroup of the batch resident, one per CU: what a step
+// waits for is its busiest CU's gather, and that is bound by the CU's rate of cache-line requests (a 32-byte row is a request
+// of its own: ~1.3 ns each measured, 128 rows x 22 neighbours = 3.7 us) -- so spread the rows over as many CUs as there are.
 bool gn_persg_plan(const gnode_graph_s* g, long rows, int H, int n_steps, PersgPlan* p) {
     const int vi = persg_vi(H);
-    if (vi < 0 || n_steps < 1 || n_steps > 127) return false;
-    if (!g->pgmap[vi]) return false;
-    const int gpw = 256 / (H / 4), wps = (g->n + gpw - 1) / gpw;
-    const long wgs = (rows / g->n) * wps;
-    if (wgs > std::min(g->num_cu, 256)) return false;              // one workgroup per CU, all resident; pers_wait sweeps 256 flags
+    if (vi < 0 || n_steps < 1 || n_steps > 127 || !g->pgmap) return false;
     if ((long)rows * H * 4 >= (1L << 31) - (1L << 17)) return false;    // 32-bit table offsets below PS_OOB
-    const int idcap = (g->pgids[vi] + 3) & ~3, segcap = std::max(4, (g->pgsegs[vi] + 3) & ~3);
-    const size_t need = sizeof(float) * ((size_t)2 * H * H + idcap + (size_t)2 * segcap * H + (size_t)segcap * 34 + 8);
-    if (need > 150 * 1024) return false;
-    if (p) { p->wgs = (int)wgs; p->wps = wps; p->idcap = idcap; p->segcap = segcap; p->lds = pg_lds_bytes(H, idcap, segcap); }
-    return true;
+    for (int nw = 1; nw <= 4; ++nw) {
+        if (g->pgoff[vi][nw - 1] < 0) continue;
+        const int gpw = (32 >> vi) * nw, wps = (g->n + gpw - 1) / gpw;
+        const long wgs = (rows / g->n) * wps;
+        if (wgs > std::min(g->num_cu, 256)) continue;              // one workgroup per CU, all resident; pers_wait sweeps 256 flags
+        const int idcap = (g->pgids[vi][nw - 1] + 3) & ~3, segcap = std::max(4, (g->pgsegs[vi][nw - 1] + 3) & ~3);
+        const size_t need = sizeof(float) * ((size_t)2 * H * H + idcap + (size_t)2 * segcap * H + (size_t)segcap * 34 + 8);
+        if (need > 150 * 1024) continue;
+        if (p) { p->wgs = (int)wgs; p->wps = wps; p->nw = nw; p->map_off = g->pgoff[vi][nw - 1]; p->idcap = idcap; p->segcap = segcap; p->lds = pg_lds_bytes(H, idcap, segcap); }
+        return true;
+    }
+    return false;
 }
 
 int gn_persg_set_attributes() {
@@ -489,7 +547,8 @@ int gn_persg_set_attributes() {
 static void persg_common(PersgArgs& a, const gnode_graph_s* g, const PersgPlan& pl, long rows, int H, const gnode_params* p, void* ctl) {
     a.rowptr = g->rowptr; a.col = g->col; a.hubidx = g->n_hub > 0 ? g->hubidx : nullptr; a.hub_seg_ptr = g->hub_seg_ptr;
     a.seg_lo = g->seg_lo; a.seg_hi = g->seg_hi;
-    a.rowmap = g->pgmap[persg_vi(H)];
+    (void)H;
+    a.rowmap = g->pgmap + pl.map_off;
     a.n = g->n; a.wgs = pl.wgs; a.wps = pl.wps; a.segcap = pl.segcap; a.idcap = pl.idcap; a.rows = (unsigned)rows;
     a.W = p->odefunc_linear_weight; a.bias = p->odefunc_linear_bias;
     a.w3 = p->linear3_weight; a.b3 = p->linear3_bias; a.w2 = p->linearS2_weight; a.b2 = p->linearS2_bias;
@@ -508,9 +567,9 @@ int gn_launch_persg(const gnode_graph_s* g, const PersgPlan& pl, long rows, int 
     for (int k = 0; k < n_steps; ++k) { a.sched.dt[k] = dt_host[k]; a.sched.slot[k] = (short)slot_host[k]; }
     if (int e = gn_pers64_zero_ctl(ctl, st)) return e;             // flags and the give-up word: zeroed before EVERY launch
     const dim3 grid((unsigned)pl.wgs);
-    if (H == 8) hipLaunchKernelGGL(k_persg<2>, grid, dim3(256), pl.lds, st, a);
-    else if (H == 16) hipLaunchKernelGGL(k_persg<4>, grid, dim3(256), pl.lds, st, a);
-    else hipLaunchKernelGGL(k_persg<8>, grid, dim3(256), pl.lds, st, a);
+    if (H == 8) hipLaunchKernelGGL(k_persg<2>, grid, dim3(64 * pl.nw), pl.lds, st, a);
+    else if (H == 16) hipLaunchKernelGGL(k_persg<4>, grid, dim3(64 * pl.nw), pl.lds, st, a);
+    else hipLaunchKernelGGL(k_persg<8>, grid, dim3(64 * pl.nw), pl.lds, st, a);
     GN_LAUNCH_CHECK();
     return 0;
 }
@@ -528,9 +587,9 @@ int gn_launch_persg_bwd(const gnode_graph_s* g, const PersgPlan& pl, long rows, 
     for (int i = 1; i <= G - 1; ++i) { a.sched.dt[i] = dt_host[i - 1]; a.sched.slot[i] = (short)slot_of_prev[i]; }
     if (int e = gn_pers64_zero_ctl(ctl, st)) return e;
     const dim3 grid((unsigned)pl.wgs);
-    if (H == 8) hipLaunchKernelGGL(k_persg_bwd<2>, grid, dim3(256), pl.lds, st, a);
-    else if (H == 16) hipLaunchKernelGGL(k_persg_bwd<4>, grid, dim3(256), pl.lds, st, a);
-    else hipLaunchKernelGGL(k_persg_bwd<8>, grid, dim3(256), pl.lds, st, a);
+    if (H == 8) hipLaunchKernelGGL(k_persg_bwd<2>, grid, dim3(64 * pl.nw), pl.lds, st, a);
+    else if (H == 16) hipLaunchKernelGGL(k_persg_bwd<4>, grid, dim3(64 * pl.nw), pl.lds, st, a);
+    else hipLaunchKernelGGL(k_persg_bwd<8>, grid, dim3(64 * pl.nw), pl.lds, st, a);
     GN_LAUNCH_CHECK();
     return 0;
 }

@@ -37,5 +37,14 @@ for name, n, m, H, tail in (("batch of 8 graphs (ER)", 22125, 249150, 8, 0.0), (
         out[tag + "_train_fwd_ms"] = round(ev_ms(lambda: ops.forward(g, x, P, dts, "euler", rows, want_sol=True, persist=pf)), 4)
         sol = ops.forward(g, x, P, dts, "euler", rows, want_sol=True, persist=pf)[3]
         out[tag + "_bwd_ms"] = round(ev_ms(lambda: ops.backward(g, x, P, dts, "euler", rows, sol, *gs, persist=pf)), 4)
+    if "--prof" in sys.argv and out["path"] == 3:          # library built with GNODE_EXTRA_FLAGS=-DGN_PERS_PROF
+        import ctypes as C
+        ops.forward(g, x, P, dts, "euler", rows, persist=True)
+        torch.cuda.synchronize()
+        ws = ops.forward.last_workspace[3]
+        tk = (C.c_uint64 * 8)()
+        ops._lib.load().gnode_forward_phase_ticks(C.c_int64(n), H, 0, C.c_void_p(ws.data_ptr()), tk)
+        names = ["Z_S mlp", "wait", "hub segments", "gather", "update + Z_I mlp + store", "drain + barrier + flag", "outputs"]
+        out["phase_us_per_step (workgroup 0)"] = {nm: round(tk[i] / 100.0 / len(dts), 3) for i, nm in enumerate(names)}
     out["status"] = ops.forward_status()
     print(json.dumps(out), flush=True)
