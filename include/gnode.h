@@ -142,14 +142,14 @@ int gnode_rhs_f32(gnode_graph_t g, const float* x, const float* W, const float* 
 #define GNODE_SOL_TINY 4   /* produced by the one-workgroup-per-sample forward: no A*Z_I anywhere, keep holds the sigmoids only */
 size_t gnode_forward_workspace_bytes(gnode_graph_t g, int64_t rows, int32_t H, int32_t method);
 /* Which form gnode_forward_f32 runs for this shape: 0 = one launch per step, 1 = the one-workgroup-per-sample launch (tiny
- * graphs in batches too large for one resident grid), 2 = the persistent launch (tiny and mid-size graphs) (then plan_host, if given, receives {16-row tiles per
- * workgroup, workgroups per sample, XCDs per sample, samples side by side per XCD, samples alive at once}); -1 = bad
- * arguments.  n_out: emitted grid points; with_sol: a trajectory is requested (training). */
+ * graphs in batches too large for one resident grid), 2 = the persistent launch (H = 64: tiny and mid-size graphs) (then plan_host, if given, receives {16-row tiles per
+ * workgroup, workgroups per sample, XCDs per sample, samples side by side per XCD, samples alive at once}), 3 = the persistent
+ * launch of the small hidden sizes (H = 8, 16, 32; batches that fit one resident grid); -1 = bad arguments.  n_out: emitted grid points; with_sol: a trajectory is requested (training). */
 int gnode_forward_path(gnode_graph_t g, int64_t rows, int32_t H, int32_t method, int32_t n_steps, int32_t n_out,
                        int32_t with_sol, int32_t flags, int32_t* plan_host);
 /* Synchronises `stream` and writes 0 to *code_host, or the give-up code of the last gnode_forward_f32 call that ran the
  * persistent path on this workspace (then its outputs are invalid).  Meaningful only after a call for which
- * gnode_forward_path() says 2 (the other forms never touch the control block).  Not capturable. */
+ * gnode_forward_path() says 2 or 3 (the other forms never touch the control block).  Not capturable. */
 int gnode_forward_status(int64_t rows, int32_t H, int32_t method, const void* workspace, void* stream, int32_t* code_host);
 /* 1 when gnode_forward_f32 (method 0, no `keep` buffer) on this graph stores A*Z_I(y_k) in the 4th slab of sol[k],
  * 1 <= k <= n_steps-1 (see `sol` below), 0 when the 4th slab repeats beta, gamma at every grid point.  n_out: number
