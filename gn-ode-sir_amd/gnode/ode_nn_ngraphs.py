@@ -41,7 +41,13 @@ class ODEfunc(nn.Module):
     def graph_for(self, marker: torch.Tensor) -> DeviceGraph:
         """marker = x[3,:,2] (or x[:,5] of the 2-D input): one host sync per forward."""
         nz = torch.nonzero(marker).flatten()
-        picks = tuple(int(v) - 1 for v in marker[nz].to(torch.int64).tolist())
+        return self.graph_for_picks(tuple(int(v) - 1 for v in marker[nz].to(torch.int64).tolist()))
+
+    def graph_for_picks(self, picks) -> DeviceGraph:
+        """The concatenated graph of a batch whose samples sit on graphs `picks` (indices into A_list), in order: what
+        graph_for reads off the markers, for callers that already know the composition (the trainer reads each sample's
+        marker ONCE: its batches are fixed, and a host read-back per forward keeps the host from running ahead)."""
+        picks = tuple(int(v) for v in picks)
         g = self._cache.get(picks)
         if g is None:
             g = DeviceGraph(*concat_csr([self._csr[p] for p in picks]))
@@ -88,9 +94,10 @@ class ODEBlock(nn.Module):
                 "linear3.weight": self.linear3.weight, "linear3.bias": self.linear3.bias,
                 "linearS2.weight": self.linearS2.weight, "linearS2.bias": self.linearS2.bias}
 
-    def forward(self, x, out_rows=None):
-        """x [sumN, 3+H] -> (S, I, R), each [G, sumN, 1] (reference :124-152)."""
-        g = self.odefunc.graph_for(x[:, 3 + 2])
+    def forward(self, x, out_rows=None, picks=None):
+        """x [sumN, 3+H] -> (S, I, R), each [G, sumN, 1] (reference :124-152).  picks: the batch's graph indices when the
+        caller knows them (else they are read off the markers: one host sync)."""
+        g = self.odefunc.graph_for_picks(picks) if picks is not None else self.odefunc.graph_for(x[:, 3 + 2])
         if g.n != x.size(0):
             raise ValueError(f"markers describe {g.n} nodes but the batch has {x.size(0)}")
         from .autograd import forward_with_grad

@@ -147,6 +147,7 @@ class Runner:
             use_graphs = os.environ.get("GNODE_TRAIN_GRAPHS", "1") != "0"
         self.use_graphs = bool(use_graphs) and stack and torch.cuda.is_available() and str(device).startswith("cuda")
         self._graphs = {}
+        self._marks, self._picks = {}, None
         on_gpu = torch.cuda.is_available() and str(device).startswith("cuda")
         # same Adam as the reference (:442); on the GPU the whole update is ONE kernel instead of ~16 tiny ones
         self.opt = torch.optim.Adam(model.parameters(), lr=lr, fused=True) if on_gpu else torch.optim.Adam(model.parameters(), lr=lr)
@@ -191,10 +192,23 @@ class Runner:
             return None, None
         x = torch.stack([xs[j] for j in mine]) if self.stack else torch.cat([xs[j] for j in mine], 0)
         y = torch.cat([ys[j] for j in mine], 0)
+        # multi-graph batches: which graph each sample sits on (its marker, ode_nn_ngraphs.py:333) is read ONCE per sample, not
+        # once per forward -- the batches are fixed and a host read-back per step keeps the host from running ahead
+        self._picks = None if self.stack else tuple(self._mark(xs[j]) for j in mine)
         return x.to(self.device), y.to(self.device)
 
+    def _mark(self, xj):
+        m = self._marks.get(id(xj))
+        if m is None or m[0] is not xj:
+            m = (xj, int(xj[0, 3 + 2].item()) - 1)          # (the tensor is kept so that its id stays its own)
+            self._marks[id(xj)] = m
+        return m[1]
+
     def _loss_sum(self, x, y):
-        S, I, R = self.model(x, out_rows=self.rows)
+        if not self.stack and self._picks:
+            S, I, R = self.model(x, out_rows=self.rows, picks=self._picks)
+        else:
+            S, I, R = self.model(x, out_rows=self.rows)
         # L1 over cat(S, I, R)[rows, T, 3][:, 1:, :] (t = 0 excluded, :234) and its gradient: one kernel instead of the
         # cat / transpose / convert / subtract / abs / sum chain and its six backward launches
         from .autograd import l1_loss_sum
