@@ -12,5 +12,7 @@ rm -rf $OUT/prof_persist
 cd $R
 bash tools/gpu_persist_prof.sh 2>/dev/null | grep '^{' > $OUT/${tag}_persist_phases.jsonl
 BENCH_ARGS=--tail bash tools/gpu_persist_prof.sh 2>/dev/null | grep '^{' >> $OUT/${tag}_persist_phases.jsonl
+timeout -k 10 300 python tools/bench_small_h.py 2>/dev/null | grep '^{' > $OUT/${tag}_bench_small_h.jsonl
+bash tools/gpu_small_h_prof.sh 2>/dev/null | grep '^{' > $OUT/${tag}_small_h_phases.jsonl
 head -12 $OUT/${tag}_persist_kernel_stats.csv | cut -c1-50,100-105 | head -3
 wc -l $OUT/${tag}_*.jsonl
