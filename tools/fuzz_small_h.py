@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Randomised cross-checks of the small-hidden-size persistent launches (csrc/gnode_persg.hip) on the GPU box: random graphs
+(ER and Chung-Lu with hub rows, isolated nodes, n around the 8 / 16 / 32 / 64 / 96 / 128-row workgroup boundaries), B = 1 .. 6,
+H in {8, 16, 32}, 1 .. 9 steps, arbitrary emitted grid points --
+  * persistent forward == one launch per step, bit for bit (outputs and trajectory), and within 1e-5 of the C restatement
+    of the reference path;
+  * persistent adjoint sweep vs one launch per interval: 2e-5 of each gradient's scale.
+usage: python tools/fuzz_small_h.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(R, "gn-ode-sir_amd"), os.path.join(R, "oracle")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+import gnode_oracle as O  # noqa: E402
+import oracle_c as OC  # noqa: E402
+from gnode import ops  # noqa: E402
+from gnode.graph import DeviceGraph  # noqa: E402
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    dev = torch.device("cuda:0")
+    worst_f = worst_b = 0.0
+    n_pers = 0
+    for c in range(cases):
+        n = int(rng.choice([3, 7, 8, 9, 16, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 300, 1000, 1893, 4097, int(rng.integers(10, 9000))]))
+        B = int(rng.integers(1, 7))
+        H = int(rng.choice([8, 8, 8, 16, 32]))
+        deg = float(rng.choice([1.0, 3.0, 7.0, 14.0, 30.0]))
+        m = min(int(n * deg / 2) + 1, max(1, int(0.7 * n * (n - 1) / 2)))
+        skew = rng.random() < 0.5
+        rp, ci, _ = (O.chung_lu_graph if skew else O.er_graph)(n, m, seed=int(rng.integers(1 << 30)))
+        n_steps = int(rng.integers(1, 10))
+        grid = np.arange(0, (n_steps + 1) * 0.5, 0.5)[: n_steps + 1]
+        dts = ops.step_sizes(grid)
+        G = n_steps + 1
+        out_rows = None
+        if rng.random() < 0.6:
+            k = int(rng.integers(1, G + 1))
+            out_rows = np.sort(rng.choice(G, size=k, replace=False)).astype(np.int32)
+        n_out = G if out_rows is None else len(out_rows)
+        P = O.init_params(H, seed=int(rng.integers(1 << 30)))
+        x = O.make_samples(n, B, H, seed=int(rng.integers(1 << 30)))
+        g = DeviceGraph(rp, ci)
+        Pt = {k: torch.from_numpy(v).to(dev) for k, v in P.items()}
+        x2d = torch.from_numpy(x).to(dev).reshape(B * n, 3 + H)
+        path = ops.forward_path(g, B * n, H, n_steps, n_out)[0]
+        r0 = ops.forward(g, x2d, Pt, dts, "euler", out_rows, want_sol=True, persist=False)
+        r1 = ops.forward(g, x2d, Pt, dts, "euler", out_rows, want_sol=True, persist=True)
+        assert ops.forward_status() == 0, (c, "a persistent launch gave up")
+        for a, b in zip(r0, r1):
+            assert torch.equal(a, b), (c, n, B, H, n_steps, "persistent forward differs from per-step", float((a - b).abs().max()))
+        ri = ops.forward(g, x2d, Pt, dts, "euler", out_rows, persist=True)
+        assert all(torch.equal(a, b) for a, b in zip(ri[:3], r1[:3])), (c, "inference instance differs")
+        n_pers += path == 3
+        # against the C restatement of the reference path (sample 0)
+        Sc, Ic, Rc = OC.forward_euler(rp, ci, n, x, P, dts)
+        sel = np.arange(G) if out_rows is None else out_rows
+        e = max(float(np.abs(r1[j].cpu().numpy().astype(np.float64) - want[sel, :, 0]).max()) for j, want in enumerate((Sc, Ic, Rc)))
+        if e > 1e-5:
+            # fp32 restatements drift apart on graphs with long rows (segment-blocked vs sequential sums): the float64 run of the
+            # same recurrence says which side is off; the GPU is held to the C oracle's own distance from it
+            with O.precision(np.float64):
+                ref64 = O.odeblock_forward_single(x.astype(np.float64), {k: v.astype(np.float64) for k, v in P.items()}, rp, ci, (n_steps + 1) * 0.5, 0.5)
+            eg = max(float(np.abs(r1[j].cpu().numpy().astype(np.float64) - np.asarray(ref64[j])[sel, :, 0]).max()) for j in range(3))
+            ec = max(float(np.abs(want[sel, :, 0].astype(np.float64) - np.asarray(ref64[j])[sel, :, 0]).max()) for j, want in enumerate((Sc, Ic, Rc)))
+            print(f"case {c}: GPU vs C {e:.2e}; vs float64: GPU {eg:.2e}, C oracle {ec:.2e} (max degree {int(np.diff(rp).max())})", flush=True)
+            assert eg <= max(2 * ec, 1e-5), (c, n, B, H, n_steps, e, eg, ec)
+            e = min(e, eg)
+        worst_f = max(worst_f, e)
+        gs = [torch.randn(n_out, B * n, device=dev) for _ in range(3)]
+        ref = ops.backward(g, x2d, Pt, dts, "euler", out_rows, r1[3], *gs, persist=False)
+        got = ops.backward(g, x2d, Pt, dts, "euler", out_rows, r1[3], *gs, persist=True)
+        gmax = max(float(v.abs().max()) for v in ref.values())
+        for k in ref:
+            # (the head's bias gradients are sums that cancel exactly when every ReLU is active -- softmax shift invariance --:
+            #  what is computed there is rounding noise, on the scale of the gradients it cancels from)
+            scale = max(float(ref[k].abs().max()), 1e-1 * gmax) + 1e-30
+            err = float((got[k] - ref[k]).abs().max()) / scale
+            worst_b = max(worst_b, err)
+            assert err <= 2e-5, (c, n, B, H, n_steps, k, err)
+        if c % 20 == 19:
+            print(f"case {c + 1}: persistent {n_pers}, worst forward vs oracle {worst_f:.2e}, worst gradient rel {worst_b:.2e}", flush=True)
+    print(f"OK {cases} cases ({n_pers} on the persistent path), worst forward vs C oracle {worst_f:.2e}, worst gradient rel {worst_b:.2e}")
+
+
+if __name__ == "__main__":
+    main()
