@@ -1180,6 +1180,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     float* red = (float*)(ws + 8 * slab_b + 2 * vec_b + gn_align((size_t)BWD_NWG * L.total() * sizeof(float)));
     void* hub_scratch = ws + backward_fixed_bytes(rows, H);
     int slots_used = 1;                                  // highest workgroup slot any launch wrote, for the final reduction
+    bool ran_persistent = false;                         // a persistent sweep zeroes and owns the control block; otherwise its give-up word is cleared below
     // what the forward that produced `sol` / `keep` was (its sol_info says so; unchecked callers: the same question, same flags)
     const int n_emit = out_rows_host ? n_out : n_steps + 1;
     const bool fwd_tiny = sol_info >= 0 ? (sol_info & GNODE_SOL_TINY) != 0 : gn_forward_kind(g, rows, H, 0, n_steps, n_emit, true, flags, nullptr) == 1;
@@ -1268,6 +1269,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                     return e;
                 if (sampled) gn_prof_end(2, st);
                 slots_used = std::max(slots_used, pslots);
+                ran_persistent = true;
                 break;
             }
             const int cur = (G - 1 - i) & 1;
@@ -1331,6 +1333,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                 return e;
             if (sampled) gn_prof_end(2, st);
             slots_used = std::max(slots_used, gp.wgs);
+            ran_persistent = true;
         } else
         slots_used = std::max(slots_used, grid);
         for (int i = gpersist ? 0 : G - 1; i >= 1; --i) {
@@ -1384,6 +1387,10 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         GN_LAUNCH_CHECK();
     }
     }   // !tiny
+    if (!ran_persistent && (H == 64 || H <= 32)) {       // gnode_backward_status() then reads 0, whatever the workspace held
+        PersCtl* ctl = (PersCtl*)(ws + backward_fixed_bytes(rows, H) - gn_pers64_ctl_bytes());
+        if (int e = gn_zero_async(ctl->error, sizeof(ctl->error), st)) return e;
+    }
     // slot layout order == PartLayout order: W, b, w3, b3, w2, b2, w1, b1
     GradDst gd;
     gd.dst[0] = (float*)grads->odefunc_linear_weight; gd.dst[1] = (float*)grads->odefunc_linear_bias;
@@ -1394,5 +1401,19 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     for (int k = 0; k < 9; ++k) gd.off[k] = offs[k];
     hipLaunchKernelGGL(k_reduce_parts, dim3((L.total() + 15) / 16), dim3(256), 0, st, part, slots_used, L.total(), gd);
     GN_LAUNCH_CHECK();
+    return 0;
+}
+
+// The persistent adjoint sweeps' give-up word (the control block at the end of the fixed part of the backward workspace).
+extern "C" int gnode_backward_status(int64_t rows, int32_t H, const void* workspace, void* stream, int32_t* code_host) {
+    GN_CHECK_ARG(workspace && code_host && rows > 0, "gnode_backward_status: null pointer");
+    *code_host = 0;
+    if (H != 64 && H > 32) return 0;
+    unsigned err[2] = {0, 0};
+    const PersCtl* ctl = (const PersCtl*)((const char*)workspace + backward_fixed_bytes(rows, H) - gn_pers64_ctl_bytes());
+    GN_HIP(hipMemcpyAsync(err, ctl->error, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GN_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *code_host = (int32_t)err[0];
+    if (err[0]) gnode_set_error("persistent adjoint sweep: a workgroup gave up waiting for epoch %u of its group", err[1]);
     return 0;
 }

@@ -17,7 +17,7 @@ EXPORTS = [
     "gnode_last_error", "gnode_version",
     "gnode_graph_create", "gnode_graph_destroy", "gnode_graph_info",
     "gnode_rhs_workspace_bytes", "gnode_rhs_f32",
-    "gnode_forward_workspace_bytes", "gnode_forward_f32", "gnode_forward_status", "gnode_forward_path", "gnode_sol_carries_neighbour_sums", "gnode_forward_keep_bytes",
+    "gnode_forward_workspace_bytes", "gnode_forward_f32", "gnode_forward_status", "gnode_backward_status", "gnode_forward_path", "gnode_sol_carries_neighbour_sums", "gnode_forward_keep_bytes",
     "gnode_backward_workspace_bytes", "gnode_backward_f32",
     "gnode_sir_workspace_bytes", "gnode_sir_coins_workspace_bytes",
     "gnode_sir_mc_philox", "gnode_sir_mc_philox_scan", "gnode_sir_mc_philox_counted", "gnode_sir_mc_coins",
@@ -74,6 +74,8 @@ def load():
     lib.gnode_forward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, sz, i64, i32, vp, sz, vp, i32, C.POINTER(i32)]
     lib.gnode_forward_status.argtypes = [i64, i32, i32, vp, vp, C.POINTER(i32)]
     lib.gnode_forward_status.restype = C.c_int
+    lib.gnode_backward_status.argtypes = [i64, i32, vp, vp, C.POINTER(i32)]
+    lib.gnode_backward_status.restype = C.c_int
     lib.gnode_forward_path.argtypes = [vp, i64, i32, i32, i32, i32, i32, i32, C.POINTER(i32)]
     lib.gnode_forward_path.restype = C.c_int
     lib.gnode_meanfield_workspace_bytes.argtypes = [vp]

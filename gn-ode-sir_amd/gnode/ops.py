@@ -141,7 +141,10 @@ def forward_path(graph: DeviceGraph, rows: int, H: int, n_steps: int, n_out: int
 
 def forward_status() -> int:
     """0, or the give-up code of the persistent launch behind the LAST `forward` call (synchronises the stream)."""
-    rows, H, m, ws, path = forward.last_workspace
+    last = getattr(forward, "last_workspace", None)
+    if last is None:
+        return 0
+    rows, H, m, ws, path = last
     if path not in (2, 3):
         return 0                                 # (the control block is only written by the persistent launch)
     code = C.c_int32(0)
@@ -184,7 +187,19 @@ def backward(graph: DeviceGraph, x2d: torch.Tensor, params: dict, dts: np.ndarra
         _lib.ptr(_f32c(gS)), _lib.ptr(_f32c(gI)), _lib.ptr(_f32c(gR)), C.byref(gp), rows, H,
         _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), 0 if (PERSIST_DEFAULT if persist is None else persist) else FWD_PER_STEP,
         int(getattr(sol, "gnode_info", -1))))
+    backward.last_workspace = (rows, H, ws)
     return grads
+
+
+def backward_status() -> int:
+    """0, or the give-up code of the persistent adjoint sweep behind the LAST `backward` call (synchronises the stream)."""
+    last = getattr(backward, "last_workspace", None)
+    if last is None:
+        return 0
+    rows, H, ws = last
+    code = C.c_int32(0)
+    _lib.check(_lib.load().gnode_backward_status(rows, H, _lib.ptr(ws), _lib.stream_ptr(), C.byref(code)))
+    return int(code.value)
 
 
 def l1_loss_sum(S: torch.Tensor, I: torch.Tensor, R: torch.Tensor, y: torch.Tensor, t0: int = 1, want_sign: bool = True):

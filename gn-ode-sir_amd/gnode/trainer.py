@@ -272,7 +272,18 @@ class Runner:
             items += gcount
         if self.collective:
             torch.distributed.all_reduce(tot_t)
+        self._check_launches()
         return float(tot_t) / max(items, 1), t_fwd
+
+    def _check_launches(self):
+        """Once per epoch (there is a host sync here anyway): did a persistent launch give up waiting for its group?  Its spins
+        are bounded so that a lost workgroup becomes this error instead of a hang (csrc/gnode_pers64.hip, gnode_persg.hip)."""
+        if not (torch.cuda.is_available() and str(self.device).startswith("cuda")):
+            return
+        f, b = ops.forward_status(), ops.backward_status()
+        if f or b:
+            raise RuntimeError(f"a persistent launch gave up (forward code {f}, backward code {b}): its outputs are invalid -- "
+                               "is another process using this GPU?  GNODE_PERSIST=0 runs one launch per step")
 
     @torch.no_grad()
     def evaluate(self, xs, ys, batch_size):
@@ -291,6 +302,7 @@ class Runner:
         if self.collective:
             torch.distributed.all_reduce(allsum)
         vals = allsum.cpu().tolist()
+        self._check_launches()
         per_batch = [v / max(c, 1) for v, c in zip(vals, counts)]
         return sum(vals) / max(sum(counts), 1), per_batch
 

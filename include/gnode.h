@@ -151,6 +151,9 @@ int gnode_forward_path(gnode_graph_t g, int64_t rows, int32_t H, int32_t method,
  * persistent path on this workspace (then its outputs are invalid).  Meaningful only after a call for which
  * gnode_forward_path() says 2 or 3 (the other forms never touch the control block).  Not capturable. */
 int gnode_forward_status(int64_t rows, int32_t H, int32_t method, const void* workspace, void* stream, int32_t* code_host);
+/* The same for the last gnode_backward_f32 call on this workspace: the give-up code of its persistent adjoint sweep, 0 when
+ * all went well or the call ran no persistent launch (every call leaves the word defined).  Not capturable. */
+int gnode_backward_status(int64_t rows, int32_t H, const void* workspace, void* stream, int32_t* code_host);
 /* 1 when gnode_forward_f32 (method 0, no `keep` buffer) on this graph stores A*Z_I(y_k) in the 4th slab of sol[k],
  * 1 <= k <= n_steps-1 (see `sol` below), 0 when the 4th slab repeats beta, gamma at every grid point.  n_out: number
  * of emitted grid points (n_steps+1 when out_rows_host is NULL). */

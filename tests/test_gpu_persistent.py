@@ -266,3 +266,20 @@ def test_small_hidden_persistent_backward(n, m, B, H, tail, dev):
     for k in ref:
         scale = float((ref["linearS2.weight"] if k == "linearS2.bias" else ref[k]).abs().max()) + 1e-30
         assert float((got[k] - ref[k]).abs().max()) / scale <= 1e-5, k
+
+
+def test_status_words_are_defined_after_every_call(dev):
+    """gnode_forward_status / gnode_backward_status: 0 after persistent and per-step calls alike (the backward clears the
+    give-up word when it ran no persistent sweep: a fresh workspace holds anything)"""
+    import torch
+    from gnode import ops
+    for H, n, m in ((64, 600, 2400), (8, 900, 4000)):
+        g, P, x = _setup_h(n, m, 2, H, 17, dev)
+        dts = ops.step_sizes(ops.time_grid(6, 0.5))
+        gs = [torch.randn(len(dts) + 1, 2 * n, device=dev) for _ in range(3)]
+        for persist in (True, False):
+            torch.empty(64 << 20, dtype=torch.uint8, device=dev).fill_(0xAB)        # dirty the allocator's blocks
+            S, I, R, sol = ops.forward(g, x, P, dts, "euler", None, want_sol=True, persist=persist)
+            assert ops.forward_status() == 0
+            ops.backward(g, x, P, dts, "euler", None, sol, *gs, persist=persist)
+            assert ops.backward_status() == 0
