@@ -44,7 +44,7 @@ int gn_zero_async(void* p, size_t bytes, hipStream_t st) {
     GN_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gnode_version(void) { return 220; }   // 220: forward takes flags + reports what sol / keep carry (sol_info), backward checks it; persistent one-launch path for mid-size graphs; 200: workspace sizes take the graph handle (hub scratch is carved from the caller's workspace); 210: forward / backward take the optional kept-activation buffer
+extern "C" int gnode_version(void) { return 221; }   // 221: gnode_backward_status, persistent launches for hidden 8 / 16 / 32 (gnode_forward_path kind 3); 220: forward takes flags + reports what sol / keep carry (sol_info), backward checks it; persistent one-launch path for mid-size graphs; 200: workspace sizes take the graph handle (hub scratch is carved from the caller's workspace); 210: forward / backward take the optional kept-activation buffer
 
 // --------------------------------------------------------------------------- instrumentation
 // HIP-event pairs around every launch of the two step kernels while enabled

@@ -110,8 +110,8 @@ def load():
     for fn in ("gnode_graph_create", "gnode_graph_destroy", "gnode_graph_info", "gnode_rhs_f32", "gnode_forward_f32",
                "gnode_sir_mc_philox", "gnode_sir_mc_coins"):
         getattr(lib, fn).restype = C.c_int
-    if lib.gnode_version() < 220:
-        raise GnodeError(f"{LIB_PATH} is stale (ABI {lib.gnode_version()} < 220): rebuild it (gnode.build.build_lib)")
+    if lib.gnode_version() < 221:
+        raise GnodeError(f"{LIB_PATH} is stale (ABI {lib.gnode_version()} < 221): rebuild it (gnode.build.build_lib)")
     _lib = lib
     return lib
 
