@@ -30,6 +30,7 @@
 #include "gnode_pers64.h"
 #include "gnode_pers64_dev.h"
 #include <algorithm>
+#include <queue>
 #include <vector>
 
 template <bool PRJ, int NT, bool SC1ST, bool HUBS>
@@ -262,21 +263,25 @@ int gn_pers64_build(gnode_graph_s* g, const int32_t* rowptr_host) {
     for (int i = 0; i < 3; ++i) {
         const int nt = 1 << i, per_wg = 16 * nt, wgs = (g->n + per_wg - 1) / per_wg, quads_per_wg = 4 * nt;
         std::vector<int32_t> map((size_t)wgs * per_wg, -1);
-        // hub rows first, ONE AT A TIME round-robin (their segment sums are work for the owner's workgroup: the biggest hubs
-        // must not share one), then the other rows in quads of neighbouring lengths, round-robin over the workgroups with room
+        // Rows go to the workgroups longest first, each to the workgroup with the fewest EDGES so far that still has a slot
+        // (longest-processing-time greedy): a step waits for its busiest workgroup, whose gather time follows the rows it has to
+        // read -- hub rows included, their segments are summed by the owner's workgroup.  The two biggest hubs never share a
+        // workgroup, the workgroup of a big hub gets short ordinary rows, and a workgroup's rows come out in descending
+        // length, so the four rows of a wave are of neighbouring lengths (a wave issues loads as far as its longest row needs).
         std::vector<int> fill((size_t)wgs, 0);
         int32_t nh = 0;
         while (nh < g->n && deg(order[nh]) > GN_HUB_T) ++nh;
         if ((long)nh > (long)wgs * per_wg / 2) { continue; }   // (half the slots hubs: not a graph for this path)
-        for (int32_t h = 0; h < nh; ++h) { const int wg = h % wgs; map[(size_t)wg * per_wg + fill[wg]++] = order[h]; }
         {
-            int wg = 0;
-            for (int32_t r = nh; r < g->n;) {
-                int guard = 0;
-                while (fill[wg] >= per_wg && guard++ < wgs) wg = (wg + 1) % wgs;
-                if (fill[wg] >= per_wg) return GNODE_ERR_ARG;   // cannot happen: wgs * per_wg >= n
-                for (int j = 0; j < 4 && r < g->n && fill[wg] < per_wg; ++j) map[(size_t)wg * per_wg + fill[wg]++] = order[r++];
-                wg = (wg + 1) % wgs;
+            typedef std::pair<long, int> WL;                   // (edges so far, workgroup)
+            std::priority_queue<WL, std::vector<WL>, std::greater<WL>> heap;
+            for (int wg = 0; wg < wgs; ++wg) heap.push(WL(0, wg));
+            for (int32_t r = 0; r < g->n; ++r) {
+                if (heap.empty()) return GNODE_ERR_ARG;        // cannot happen: wgs * per_wg >= n
+                const WL w = heap.top();
+                heap.pop();
+                map[(size_t)w.second * per_wg + fill[w.second]++] = order[r];
+                if (fill[w.second] < per_wg) heap.push(WL(w.first + std::max(1, deg(order[r])), w.second));
             }
         }
         (void)quads_per_wg;
