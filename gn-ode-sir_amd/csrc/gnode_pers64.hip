@@ -227,8 +227,9 @@ __global__ __launch_bounds__(256 * NT) void k_pers64(const PersArgs a) {
                 __syncthreads();
                 if (threadIdx.x == 0) __hip_atomic_store(flags + idx, ebase + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 PS_STAMP(4)
-                // Z_S(y_{k+1}) is read behind the next barrier: its matrix phase runs under the flag's flight (measured: in
-                // FRONT of the flag it delays every workgroup of the group by its full length)
+                // Z_S(y_{k+1}) is read behind the next barrier: its matrix phase runs under the flag's flight (measured twice: in
+                // FRONT of the flag -- also between the row stores and their vmcnt(0) wait -- it delays every workgroup of the group
+                // by its full length: fb-social size B = 1 0.257 -> 0.322 ms, wiki-vote size 0.55 -> 0.59)
                 mfma_dual16<false, true>(TA, TB, Wslab, T2I, T2S, bias_l, fo, oo);
                 PS_STAMP(5)
             }
