@@ -1417,3 +1417,10 @@ extern "C" int gnode_backward_status(int64_t rows, int32_t H, const void* worksp
     if (err[0]) gnode_set_error("persistent adjoint sweep: a workgroup gave up waiting for epoch %u of its group", err[1]);
     return 0;
 }
+
+// diagnostic build (GN_PERS_PROF): per-phase 100 MHz ticks of the last persistent adjoint sweep on this workspace
+extern "C" int gnode_backward_phase_ticks(int64_t rows, int32_t H, const void* workspace, uint64_t* ticks8_host) {
+    const PersCtl* ctl = (const PersCtl*)((const char*)workspace + backward_fixed_bytes(rows, H) - gn_pers64_ctl_bytes());
+    GN_HIP(hipMemcpy(ticks8_host, ctl->prof, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -332,6 +332,9 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
 #pragma unroll
         for (int k = 0; k < H; ++k) accW[j][k] = 0.f;
     float4 accb = z0;
+#ifdef GN_PERS_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int i = G - 1; i >= 1; --i) {
         const int cur = (G - 1 - i) & 1;
         const float dt = a.sched.dt[i];
@@ -348,7 +351,9 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
                 gout[0] = a.S[o]; gout[1] = a.I[o]; gout[2] = a.R[o];
             }
         }
+        PS_STAMP(0)
         if (i < G - 1 && !pg_barrier(a.ctl, a.wgs, (unsigned)(G - 1 - i), L.meta)) return;
+        PS_STAMP(1)
         float4 ai = z0, gq = z0;
         if (items > 0) {
             for (int it = grp; it < items; it += GPW) {
@@ -362,7 +367,9 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
                 PG_ADD(ai, u) PG_ADD(gq, v)
             }
         }
+        PS_STAMP(2)
         pg_sum2<GN_PERSG_BNB>(ai, gq, zt[cur], qt[cur], L.IDS + row.estart, row.cnt, cmax, lane_b);
+        PS_STAMP(3)
         float4 dS, dI;
 #define PG_DPRE(c)                                                         \
         {                                                                  \
@@ -389,7 +396,9 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
                 pers_st<16>(qt[cur ^ 1], row.off_b, make_float4(bt * (aI.x - aS.x) * zs.x, bt * (aI.y - aS.y) * zs.y,
                                                                 bt * (aI.z - aS.z) * zs.z, bt * (aI.w - aS.w) * zs.w));
             }
+            PS_STAMP(4)
             pg_publish(a.ctl, (unsigned)(G - i));
+            PS_STAMP(5)
         }
         // behind the flag: gW += dt dpre^T y (S and I parts), gb += dt dpre
         {
@@ -408,7 +417,11 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
             accb.x += dv[0][0] + dv[1][0]; accb.y += dv[0][1] + dv[1][1]; accb.z += dv[0][2] + dv[1][2]; accb.w += dv[0][3] + dv[1][3];
         }
         zs0 = zs; zi0 = zi; yS = y[0]; yI = y[1];
+        PS_STAMP(6)
     }
+#ifdef GN_PERS_PROF
+    if (threadIdx.x == 0 && blockIdx.x == 0) for (int i = 0; i < 8; ++i) a.ctl->prof[i] = prof[i];
+#endif
     if (row.inrow) { st4(a.a + off, aS); st4(a.a + slab + off, aI); st4(a.a + 2 * slab + off, aR); }
     // ---- one reduction per sweep: lane-group accumulators -> this workgroup's partial slot, fixed order
     const PartLayout PL{H};

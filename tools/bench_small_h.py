@@ -46,5 +46,15 @@ for name, n, m, H, tail in (("batch of 8 graphs (ER)", 22125, 249150, 8, 0.0), (
         ops._lib.load().gnode_forward_phase_ticks(C.c_int64(n), H, 0, C.c_void_p(ws.data_ptr()), tk)
         names = ["Z_S mlp", "wait", "hub segments", "gather", "update + Z_I mlp + store", "drain + barrier + flag", "outputs"]
         out["phase_us_per_step (workgroup 0)"] = {nm: round(tk[i] / 100.0 / len(dts), 3) for i, nm in enumerate(names)}
+    if "--prof" in sys.argv and out["path"] == 3:
+        import ctypes as C
+        sol = ops.forward(g, x, P, dts, "euler", rows, want_sol=True, persist=True)[3]
+        ops.backward(g, x, P, dts, "euler", rows, sol, *gs, persist=True)
+        torch.cuda.synchronize()
+        ws = ops.backward.last_workspace[2]
+        tk = (C.c_uint64 * 8)()
+        ops._lib.load().gnode_backward_phase_ticks(C.c_int64(n), H, C.c_void_p(ws.data_ptr()), tk)
+        names = ["trajectory rows requested", "wait", "hub segments", "gather (2 tables)", "dpre, g_Y, head, next Z / q, store", "drain + barrier + flag", "gW, gb accumulation"]
+        out["bwd_phase_us_per_interval (workgroup 0)"] = {nm: round(tk[i] / 100.0 / len(dts), 3) for i, nm in enumerate(names)}
     out["status"] = ops.forward_status()
     print(json.dumps(out), flush=True)
