@@ -473,7 +473,10 @@ static int persg_vi(int H) { return H == 8 ? 0 : H == 16 ? 1 : H == 32 ? 2 : -1;
 
 // Row maps for workgroups of 1 .. 4 waves (a wave holds 64 / LPR rows: 32 at H = 8): rows are dealt longest first, round-robin,
 // to the sample's workgroups -- real node numberings put the big nodes next to each other, and one workgroup owning them all
-// would need their segments' ids in its LDS and set every step's duration.  Per variant: the most neighbour ids of ordinary rows and the most hub segments one workgroup
+// would need their segments' ids in its LDS and set every step's duration.  (Edge-balanced dealing -- each row to the workgroup
+// with the fewest edges so far, what gn_pers64_build does -- measured worse here: heavy-tailed wiki-vote size 0.32 -> 0.37 ms;
+// a hub's segments are spread over the workgroup's lane groups, an ordinary row is one lane group's serial chain, and the
+// snake gives every workgroup the same number of rows from every length class.)  Per variant: the most neighbour ids of ordinary rows and the most hub segments one workgroup
 // has to stage.  All maps of a graph live in ONE device allocation.
 int gn_persg_build(gnode_graph_s* g, const int32_t* rowptr_host) {
     const int n = g->n;
