@@ -284,6 +284,71 @@ def bench_train_dist(lib, dev, dist, world, rank, backend):
             "samples_per_s": world * B / float(t[0]), "weights_identical_on_all_ranks": bool(float(wmin) == float(wmax))}
 
 
+def bench_train_dist_h8(lib, dev, dist, world, rank, backend):
+    """configs[4] under N ranks (monitorer-ngraphs.py:10,20,22: hidden 8, batches of 8 graphs concatenated along the node axis, RCCL
+    gradient all-reduce): every rank trains on its own concatenated batch of 8 graphs of the five training sizes (weak scaling:
+    8 N graphs per optimiser step), local forward + adjoint sweep, ONE flat all-reduce of the 129-float gradient, identical Adam
+    step on every rank."""
+    import scipy.sparse as sp
+    import torch
+    from gnode import ops, sharding, synth
+    from gnode import ode_nn_ngraphs as multi
+    from gnode.autograd import l1_loss_sum
+    H, maxTime, deltaT = 8, 20, 0.5
+    sizes = [(62, 159), (620, 2102), (1893, 13835), (2905, 15645), (7066, 100736)]
+    csr = [synth.er_csr(n, m, seed=n) for n, m in sizes]
+    A_list = [sp.csr_matrix((np.ones(c.shape[0]), c, r), shape=(len(r) - 1, len(r) - 1)) for r, c in csr]
+    model = multi.ODEBlock(maxTime, deltaT, H, multi.ODEfunc(A_list, H, dev), dev).to(dev)
+    model.load_state_dict({**model.state_dict(), **{k: torch.from_numpy(v) for k, v in synth.linear_params(H, seed=0).items()}})
+    picks = [0, 1, 2, 3, 4, 2, 1, 4]
+    xs = []
+    for j, p in enumerate(picks):
+        xi = synth.samples(sizes[p][0], 1, H, seed=1000 * rank + j)[0]
+        xi[0, 5] = p + 1
+        xs.append(xi)
+    x = torch.from_numpy(np.concatenate(xs, 0)).to(dev)
+    tot = x.shape[0]
+    y = torch.from_numpy(np.random.default_rng(rank).dirichlet(np.ones(3), size=(tot, maxTime))).to(dev)
+    rows = ops.subsample_rows(maxTime, deltaT)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    params = list(model.parameters())
+    scale = 1.0 / (world * tot * (maxTime - 1) * 3)
+    t_ar = [0.0]
+
+    def step(time_ar):
+        opt.zero_grad()
+        S, I, R = model(x, out_rows=rows, picks=picks)
+        l1_loss_sum(S, I, R, y, 1).backward()
+        if time_ar:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        sharding.allreduce_flat_grads([p for p in params if p.grad is not None], scale=scale)
+        if time_ar:
+            torch.cuda.synchronize(); t_ar[0] += time.perf_counter() - t0
+        opt.step()
+
+    for _ in range(3):
+        step(False)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        step(False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for _ in range(reps):
+        step(True)
+    t = torch.tensor([dt / reps, t_ar[0] / reps], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    w0 = model.odefunc.linear.weight.detach().double().sum().reshape(1).to(t.device)
+    wmin, wmax = w0.clone(), w0.clone()
+    dist.all_reduce(wmin, op=dist.ReduceOp.MIN); dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
+    path = ops.forward_path(model.odefunc.graph_for_picks(picks), tot, H, len(ops.time_grid(maxTime, deltaT)) - 1, len(rows), want_sol=True)[0]
+    return {"shape": f"8 graphs (62..7066 nodes, {tot} rows) per rank x {world} ranks, H={H}, 39 Euler steps", "ms_per_step_max_over_ranks": float(t[0]) * 1e3,
+            "gradient_allreduce_ms (129 floats, flat, timed with a sync on both sides)": float(t[1]) * 1e3,
+            "graphs_per_s": world * len(picks) / float(t[0]), "weights_identical_on_all_ranks": bool(float(wmin) == float(wmax)),
+            "path": {0: "one launch per Euler step / interval", 3: "persistent one-launch (gnode_persg.hip)"}.get(path, str(path))}
+
+
 def _ev_ms(fn, reps, warm=2):
     import torch
     for _ in range(warm):
@@ -733,6 +798,10 @@ def main():
             result["train_dist"] = bench_train_dist(lib, dev, dist, world, rank, backend)
         except Exception as exc:
             result["train_dist"] = f"unavailable: {type(exc).__name__}: {exc}"
+        try:
+            result["train_dist_h8"] = bench_train_dist_h8(lib, dev, dist, world, rank, backend)
+        except Exception as exc:
+            result["train_dist_h8"] = f"unavailable: {type(exc).__name__}: {exc}"
     single = rank == 0 and world == 1
     sir_ctx = None
     if single and not args.no_secondary:
