@@ -132,10 +132,13 @@ __device__ __forceinline__ bool pers_wait(unsigned* flags, int wgs, unsigned epo
 #ifndef GN_PERS_POLL3
 #define GN_PERS_POLL3 0
 #endif
+#ifndef GN_PERS_SLEEP
+#define GN_PERS_SLEEP 1
+#endif
         unsigned f0[4], f1[4], f2[4];
         sweep(f0);
         if (GN_PERS_POLL3) { __builtin_amdgcn_s_sleep(3); sweep(f1); __builtin_amdgcn_s_sleep(3); sweep(f2); }
-        else __builtin_amdgcn_s_sleep(1);
+        else __builtin_amdgcn_s_sleep(GN_PERS_SLEEP);
         const bool o0 = all_ge(f0), o1 = GN_PERS_POLL3 && all_ge(f1), o2 = GN_PERS_POLL3 && all_ge(f2);
         if (__all(o0) || __all(o1) || __all(o2)) return true;
         if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {        // 2 s at 100 MHz
