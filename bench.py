@@ -152,27 +152,6 @@ def bench_train(lib, dev, n, m, B, H, maxTime, deltaT, reps):
         out["fwd_step_kernel_avg_us"] = fwd_ms / max(fwd_n, 1) * 1e3
         out["bwd_interval_kernel_avg_us"] = bwd_ms / max(bwd_n, 1) * 1e3
     out["path"] = {0: "one launch per Euler step", 1: "one-workgroup launch", 2: "persistent one-launch"}[path]
-    if path == 2:
-        # the same step as the product's trainer runs it (gnode/trainer.py: forward + loss + adjoint sweep captured ONCE into a HIP
-        # graph per batch shape, replayed; Adam outside): the eager number above carries ~0.17 ms of Python / autograd dispatch
-        try:
-            from gnode.trainer import Runner
-            # (a fresh model: the eager steps above left autograd nodes bound to the default stream, which a capture must not meet)
-            model2 = ODEBlock(maxTime, deltaT, n, [0], H, ODEfunc(A, 0.2, 0.1, H, dev), dev).to(dev)
-            run = Runner(model2, 1e-3, maxTime, deltaT, dev, stack=True, use_graphs=True)
-            xs, ys = [x[b].cpu() for b in range(B)] * 4, [y.view(B, n, maxTime, 3)[b].cpu() for b in range(B)] * 4
-            xp, yp = run.place(xs, ys)
-            run.train_epoch(xp, yp, B, 0)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for ep in range(3):
-                run.train_epoch(xp, yp, B, ep)
-            torch.cuda.synchronize()
-            out["trainer_step_hip_graph_ms"] = (time.perf_counter() - t0) / (3 * 4) * 1e3
-            del run, xp, yp, model2
-        except Exception as e:  # noqa: BLE001
-            out["trainer_step_hip_graph_ms"] = None
-            out["trainer_step_error"] = repr(e)[:200]
     # gradient check (not timed): the default path (kept activations; persistent launches where they apply) against the
     # recomputing backward behind one launch per Euler step / interval, same weights, same batch
     try:
