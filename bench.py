@@ -420,7 +420,7 @@ def bench_tiny(lib, dev):
            "path": {0: "one launch per Euler step", 1: "one-workgroup launch", 2: "persistent one-launch"}[ops.forward_path(model.odefunc.graph, n, H, n_steps)[0]]}
     xs = [x1.cpu()[0]] * 8
     ys = [torch.from_numpy(np.random.default_rng(0).dirichlet(np.ones(3), size=(n, maxTime)))] * 8
-    for mode in (False, True):
+    for mode in (True, False):                  # (the capture first: no autograd state of eager steps alive next to it)
         run = Runner(model, 1e-3, maxTime, deltaT, dev, stack=True, use_graphs=mode)
         xp, yp = run.place(xs, ys)
         run.train_epoch(xp, yp, 1, 0)
