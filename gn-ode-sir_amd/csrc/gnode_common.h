@@ -10,6 +10,7 @@ struct gnode_graph_s {
     int32_t n;
     int64_t nnz;
     int32_t max_degree;
+    int32_t n_bigrow; // rows longer than GN_SIR_BIGROW (the Monte-Carlo kernel walks those with the whole workgroup; their list's capacity)
     int32_t device;   // the HIP device the CSR lives on (current device at gnode_graph_create)
     int32_t num_cu;   // its compute-unit count: persistent grids are sized from the handle, not from process globals
     int32_t* rowptr;  // device [n+1]
@@ -40,6 +41,9 @@ struct gnode_graph_s {
     int32_t pgoff[3][4], pgids[3][4], pgsegs[3][4];
 };
 
+#ifndef GN_SIR_BIGROW
+#define GN_SIR_BIGROW 512     // Monte-Carlo frontier kernel: rows longer than this are walked by the whole workgroup
+#endif
 #define HUB_SEG 32           // a hub row's neighbour list is cut into segments of this many edges
 #ifndef GN_HUB_T
 #define GN_HUB_T 96          // rows longer than this are hubs (measured break-even against the two extra launches per step)

@@ -489,11 +489,12 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
     GN_CHECK_ARG(rowptr_host && out && n > 0 && nnz >= 0, "gnode_graph_create: null pointer or empty graph");
     GN_CHECK_ARG(col_host || nnz == 0, "gnode_graph_create: col is null");
     GN_CHECK_ARG(rowptr_host[0] == 0 && rowptr_host[n] == nnz, "gnode_graph_create: rowptr[0] != 0 or rowptr[n] != nnz");
-    int32_t maxdeg = 0;
+    int32_t maxdeg = 0, n_bigrow = 0;
     for (int32_t i = 0; i < n; ++i) {
         const int32_t d = rowptr_host[i + 1] - rowptr_host[i];
         GN_CHECK_ARG(d >= 0, "gnode_graph_create: rowptr not monotone at %d", i);
         maxdeg = d > maxdeg ? d : maxdeg;
+        n_bigrow += d > GN_SIR_BIGROW;
     }
     for (int64_t e = 0; e < nnz; ++e)
         GN_CHECK_ARG(col_host[e] >= 0 && col_host[e] < n, "gnode_graph_create: col[%lld]=%d out of range",
@@ -502,7 +503,7 @@ extern "C" int gnode_graph_create(const int32_t* rowptr_host, const int32_t* col
     GN_HIP(hipGetDevice(&dev));
     if (int e = gn_device_setup_once(dev)) return e;
     gnode_graph_s* g = new gnode_graph_s();
-    g->n = n; g->nnz = nnz; g->max_degree = maxdeg; g->rowptr = nullptr; g->col = nullptr; g->rowhdr = nullptr;
+    g->n = n; g->nnz = nnz; g->max_degree = maxdeg; g->n_bigrow = n_bigrow; g->rowptr = nullptr; g->col = nullptr; g->rowhdr = nullptr;
     g->n_hub = g->n_seg = 0; g->hubidx = g->seg_lo = g->seg_hi = g->hub_seg_ptr = nullptr;
     g->device = dev;
     g->num_cu = g_dev_cu[dev];

@@ -125,9 +125,7 @@ __global__ __launch_bounds__(1024) void k_sir_philox(const int* __restrict__ src
 // LDS: ever-infected bitmap (n bits) and, when they fit (uint16 ids: n up to ~25 000 -- every graph of the reference's
 // multi-graph experiment but enron and epinions), the node lists: current / next frontier and the rows too long for
 // one lane group.  Larger graphs keep the three lists in the caller's workspace (int32 ids, one set per workgroup).
-#ifndef GN_SIR_BIGROW
-#define GN_SIR_BIGROW 512     // rows longer than this are walked by the whole workgroup
-#endif
+// GN_SIR_BIGROW (gnode_common.h): rows longer than this are walked by the whole workgroup
 // COUNT: the profiling instantiation (gnode_sir_mc_philox_counted) also tallies Philox blocks, coins and CSR entries read.
 template <typename IdT, bool LISTS_IN_LDS, bool COUNT>
 __global__ __launch_bounds__(1024) void k_sir_frontier(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
@@ -150,7 +148,7 @@ __global__ __launch_bounds__(1024) void k_sir_frontier(const int* __restrict__ r
                               : reinterpret_cast<IdT*>(glists + (size_t)blockIdx.x * 3 * n);
     IdT* cur = lists;
     IdT* nxt = lists + n;
-    IdT* big = lists + 2 * (size_t)n;                          // [n] (worst case: every frontier row is long)
+    IdT* big = lists + 2 * (size_t)n;                          // [rows longer than GN_SIR_BIGROW in the graph] (LDS form), [n] (workspace form)
     __shared__ int cnt[3];                                     // [0] next-list length, [1] big-row list length, [2] ever infected
     uint32_t* hinf = hist;
     uint32_t* hrec = hist + (size_t)T * n;
@@ -451,14 +449,34 @@ __global__ void k_put_seeds(SeedArg sa, int n_seeds, int32_t* __restrict__ seeds
 
 // LDS of the frontier kernel: bitmap (+ three uint16 node lists -- current, next, long rows -- when they fit)
 static size_t frontier_bitmap_bytes(int n) { return 3 * ((((size_t)n + 31) / 32 + 3) & ~(size_t)3) * 4; }   // ever-infected + spent + recovered
-static bool frontier_lists_in_lds(int n) { return n <= 65536 && frontier_bitmap_bytes(n) + 6 * (size_t)n <= 48 * 1024; }
+// list elements in LDS: current + next frontier [n] each, long rows [as many as the graph has, padded to 8]
+static size_t frontier_list_bytes(int n, int n_big) { return 2 * (2 * (size_t)n + (((size_t)n_big + 7) & ~(size_t)7)); }
+static bool frontier_lists_in_lds(int n, int n_big) { return n <= 65536 && frontier_bitmap_bytes(n) + frontier_list_bytes(n, n_big) <= 48 * 1024; }
 // + 1 KB of coin queue per wave
-static size_t frontier_lds_bytes(int n, int threads) { return frontier_bitmap_bytes(n) + (size_t)(threads / 64) * 1024 + (frontier_lists_in_lds(n) ? 6 * (size_t)n : 0); }
-// workgroup size: the smallest of 256 / 512 / 1024 threads that still puts >= 16 waves on a CU (the LDS decides how many fit)
-static int frontier_threads(int n, int* per_cu_out) {
-    for (int threads = 256; ; threads *= 2) {
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (frontier_lds_bytes(n, threads) + 64)));
-        if (per_cu * (threads / 64) >= 16 || threads == 1024) { *per_cu_out = per_cu; return threads; }
+static size_t frontier_lds_bytes(int n, int n_big, int threads) {
+    return frontier_bitmap_bytes(n) + (size_t)(threads / 64) * 1024 + (frontier_lists_in_lds(n, n_big) ? frontier_list_bytes(n, n_big) : 0);
+}
+// Workgroup size and workgroups per CU (the LDS decides how many fit).  Measured, 10 000 x 20 (2 000 x 30 at epinions size),
+// beta 0.3 / 0.05, ms:            16 waves per CU    24 waves      32 waves
+//   fb-social size (256 threads)        --           2.90 / 4.12   3.26 / 4.14
+//   wiki-vote size (512 threads)    9.8 / 28.0       8.2 / 22.5    9.3 / 25.1
+//   epinions size  (512 threads)        --          29.5 / 36.8   35.7 / 41.9     (256 threads x 5: 37.1 / 46.8)
+// -- past 24 waves the resident trajectories thrash each other's rows in the L2, below it the waits are exposed.  So: 256
+// threads for small graphs, 512 otherwise (1 024 when the LDS leaves fewer than 16 waves), at most GN_SIR_WAVES waves per CU.
+#ifndef GN_SIR_WAVES
+#define GN_SIR_WAVES 24
+#endif
+#ifndef GN_SIR_THREADS
+#define GN_SIR_THREADS 0
+#endif
+static int frontier_threads(int n, int n_big, int* per_cu_out) {
+    for (int threads = GN_SIR_THREADS ? GN_SIR_THREADS : (n < 4096 ? 256 : 512); ; threads *= 2) {
+        int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (frontier_lds_bytes(n, n_big, threads) + 64)));
+        if (per_cu * (threads / 64) >= 16 || threads == 1024 || GN_SIR_THREADS) {
+            per_cu = std::max(1, std::min(per_cu, GN_SIR_WAVES / (threads / 64)));
+            *per_cu_out = per_cu;
+            return threads;
+        }
     }
 }
 static const int kFrontierGlobalGrid = 1024;       // workgroups that own a set of global lists (graphs past the LDS form)
@@ -481,7 +499,7 @@ extern "C" size_t gnode_sir_workspace_bytes(gnode_graph_t g, int32_t T) {
                gn_align((size_t)std::max<int64_t>(g->nnz, 1) * sizeof(int32_t));
     size_t tail = 0;                                       // one region, two users that never run together
     if ((size_t)2 * g->n > kLdsStateLimit) tail = (size_t)2048 * 2 * g->n;                                   // scan kernel, state in memory
-    if (!frontier_lists_in_lds(g->n)) tail = std::max(tail, (size_t)kFrontierGlobalGrid * 3 * g->n * sizeof(int32_t));   // frontier lists
+    if (!frontier_lists_in_lds(g->n, g->n_bigrow)) tail = std::max(tail, (size_t)kFrontierGlobalGrid * 3 * g->n * sizeof(int32_t));   // frontier lists
     return b + gn_align(tail);
 }
 
@@ -527,13 +545,13 @@ static int sir_mc_philox_impl(gnode_graph_t g, const int32_t* seeds_host, int32_
     if (sims > 0) {
         const bool sampled = gn_prof_begin(3, st);
         int per_cu_f = 1;
-        const int threads_f = frontier_threads(g->n, &per_cu_f);
-        const size_t fl = frontier_lds_bytes(g->n, threads_f);
+        const int threads_f = frontier_threads(g->n, g->n_bigrow, &per_cu_f);
+        const size_t fl = frontier_lds_bytes(g->n, g->n_bigrow, threads_f);
         const size_t lds = (size_t)2 * g->n;
         if (fl <= kLdsStateLimit && !edge_scan) {
             // frontier-driven walk.  Workgroups per CU by LDS, at least 16 waves per CU
             const int per_cu = per_cu_f, threads = threads_f;
-            if (frontier_lists_in_lds(g->n)) {
+            if (frontier_lists_in_lds(g->n, g->n_bigrow)) {
                 const int grid = (int)std::min<int64_t>(sims, (int64_t)g->num_cu * per_cu);
                 if (stats) hipLaunchKernelGGL((k_sir_frontier<uint16_t, true, true>), dim3(grid), dim3(threads), fl, st, g->rowptr, g->col, g->n, seeds,
                                               n_seeds, tb, tg, (long)sims, (long)sim_offset, T, k0, k1, hist, (int32_t*)nullptr, stats);
