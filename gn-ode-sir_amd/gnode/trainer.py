@@ -227,19 +227,23 @@ class Runner:
                 (self._loss_sum(xs, ys) / gcount).backward()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            # the captured backward CREATES the gradient tensors (in the graph's pool: fixed addresses, rewritten by every
+            # replay) instead of zero-filling and accumulating into existing ones -- 16 tiny launches less per step
+            params = [p for p in self.model.parameters()]
+            for p in params:
+                p.grad = None
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                for p in self.model.parameters():
-                    if p.grad is not None:
-                        p.grad.zero_()
                 ls = self._loss_sum(xs, ys)
                 (ls / gcount).backward()
                 ls_out = ls.detach()
-            ent = (graph, xs, ys, ls_out)
+            ent = (graph, xs, ys, ls_out, [p.grad for p in params])
             self._graphs[key] = ent
-        graph, xs, ys, ls_out = ent
+        graph, xs, ys, ls_out, grads = ent
         xs.copy_(x); ys.copy_(y)
         graph.replay()
+        for p, g in zip(self.model.parameters(), grads):       # each batch shape's graph owns its gradient tensors
+            p.grad = g
         return ls_out
 
     def train_epoch(self, xs, ys, batch_size, epoch):
@@ -250,9 +254,12 @@ class Runner:
         tot_t = torch.zeros((), dtype=torch.float64, device=self.device)
         T = ys[0].shape[1] if ys else 0
         for sel in self.batches(len(xs), batch_size, True, epoch):
-            self.opt.zero_grad(set_to_none=not self.use_graphs)
             gcount = sum(ys[j].shape[0] for j in sel) * (T - 1) * 3       # elements of the GLOBAL batch
             x, y = self._local(xs, ys, sel)
+            if not self.use_graphs:
+                self.opt.zero_grad(set_to_none=True)
+            elif x is None:
+                self.opt.zero_grad(set_to_none=False)                     # (a replay rewrites the gradients; nothing does for a rank without samples)
             if x is not None and self.use_graphs:
                 t0 = time.time()
                 tot_t += self._graphed_backward(x, y, gcount).to(torch.float64)   # grads are (re)written by the replay
