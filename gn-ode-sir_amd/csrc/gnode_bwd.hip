@@ -1180,7 +1180,6 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
     float* red = (float*)(ws + 8 * slab_b + 2 * vec_b + gn_align((size_t)BWD_NWG * L.total() * sizeof(float)));
     void* hub_scratch = ws + backward_fixed_bytes(rows, H);
     int slots_used = 1;                                  // highest workgroup slot any launch wrote, for the final reduction
-    bool ran_persistent = false;                         // a persistent sweep zeroes and owns the control block; otherwise its give-up word is cleared below
     // what the forward that produced `sol` / `keep` was (its sol_info says so; unchecked callers: the same question, same flags)
     const int n_emit = out_rows_host ? n_out : n_steps + 1;
     const bool fwd_tiny = sol_info >= 0 ? (sol_info & GNODE_SOL_TINY) != 0 : gn_forward_kind(g, rows, H, 0, n_steps, n_emit, true, flags, nullptr) == 1;
@@ -1196,9 +1195,29 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                                          keep_need > 0 ? keep : nullptr, st))
             return e;
         slots_used = (int)(rows / g->n);
+        {   // (gnode_backward_status reads a defined word after this path too)
+            PersCtl* ctl = (PersCtl*)(ws + backward_fixed_bytes(rows, H) - gn_pers64_ctl_bytes());
+            if (int e = gn_zero_async(ctl->error, sizeof(ctl->error), st)) return e;
+        }
     } else {
-    if (int e = gn_zero_async(a, 3 * slab * sizeof(float), st)) return e;
-    if (int e = gn_zero_async(part, (size_t)BWD_NWG * L.total() * sizeof(float), st)) return e;
+    // every start-up zero-fill in ONE launch: the adjoint state, the gradient slots, (H = 64) the q tables' zero rows and the
+    // control block of the persistent sweeps (they then skip their own zero-fill launch; a call that runs none leaves the
+    // give-up word at 0, which is what gnode_backward_status reads)
+    const bool has_ctl = H == 64 || H <= 32;
+    char* ctl_ptr = ws + backward_fixed_bytes(rows, H) - gn_pers64_ctl_bytes();
+    {
+        GnZeroRegions zr;
+        zr.n = 0;
+        auto add = [&](void* ptr, size_t bytes) { zr.p[zr.n] = ptr; zr.bytes[zr.n] = bytes; ++zr.n; };
+        add(a, 3 * slab * sizeof(float));
+        add(part, (size_t)BWD_NWG * L.total() * sizeof(float));
+        if (H == 64 && n_steps >= 1) {
+            add(q + slab, (size_t)H * sizeof(float));
+            add(dpre + slab_b / sizeof(float) + slab, (size_t)H * sizeof(float));
+        }
+        if (has_ctl) add(ctl_ptr, gn_pers64_ctl_bytes());
+        if (int e = gn_zero_regions_async(zr, st)) return e;
+    }
     hipLaunchKernelGGL(k_extract_bg, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, sol + 3 * slab, (long)rows, H,
                        beta, gamma);
     GN_LAUNCH_CHECK();
@@ -1227,7 +1246,7 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         // one launch per interval: a[3] | Z_S | Z_I(0) | q(0) | Z_I(1) | q(1)  (Z_S is row-local, the gather tables ping-pong)
         float* ZS = Z; float* ZIb[2] = {Z + slab, dpre};     // (k_mlp64_q fills Z_S | Z_I element-contiguously)
         float* Qb[2] = {q, dpre + slab_b / sizeof(float)};
-        for (int k = 0; k < 2; ++k) if (int e = gn_zero_async(Qb[k] + slab, (size_t)H * sizeof(float), st)) return e;   // the q tables' zero rows
+        // (the q tables' zero rows, Qb[k] + slab, were zero-filled by the call's first launch)
         const long mt = (2 * rows + TILE_ROWS - 1) / TILE_ROWS;
         hipLaunchKernelGGL(k_mlp64_q, dim3((unsigned)std::min<long>(mt, 1024)), dim3(256), 0, st, sol + (size_t)(G - 1) * 4 * slab,
                            p->odefunc_linear_weight, p->odefunc_linear_bias, Z, a, beta, q, (long)rows);
@@ -1264,12 +1283,10 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
                 int pslots = 0;
                 const bool sampled = gn_prof_begin(2, st);
                 if (int e = gn_launch_pers_bwd64(g, pplan, rows, G, Qb[0], Qb[1], sol, keep, p->odefunc_linear_weight, beta, gamma, a, part,
-                                                 gS, gI, gR, p, dt_host, slot_prev,
-                                                 ws + backward_fixed_bytes(rows, H) - gn_pers64_ctl_bytes(), &pslots, st))
+                                                 gS, gI, gR, p, dt_host, slot_prev, ctl_ptr, true, &pslots, st))
                     return e;
                 if (sampled) gn_prof_end(2, st);
                 slots_used = std::max(slots_used, pslots);
-                ran_persistent = true;
                 break;
             }
             const int cur = (G - 1 - i) & 1;
@@ -1329,11 +1346,10 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
             for (int j = 1; j <= G - 1; ++j) slot_prev[j] = slot_of(j - 1);
             const bool sampled = gn_prof_begin(2, st);
             if (int e = gn_launch_persg_bwd(g, gp, rows, H, G, ZIb[0], ZIb[1], Qb[0], Qb[1], ZS, sol, beta, gamma, a, part, gS, gI, gR, p,
-                                            dt_host, slot_prev, ws + backward_fixed_bytes(rows, H) - gn_pers64_ctl_bytes(), st))
+                                            dt_host, slot_prev, ctl_ptr, true, st))
                 return e;
             if (sampled) gn_prof_end(2, st);
             slots_used = std::max(slots_used, gp.wgs);
-            ran_persistent = true;
         } else
         slots_used = std::max(slots_used, grid);
         for (int i = gpersist ? 0 : G - 1; i >= 1; --i) {
@@ -1387,10 +1403,6 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         GN_LAUNCH_CHECK();
     }
     }   // !tiny
-    if (!ran_persistent && (H == 64 || H <= 32)) {       // gnode_backward_status() then reads 0, whatever the workspace held
-        PersCtl* ctl = (PersCtl*)(ws + backward_fixed_bytes(rows, H) - gn_pers64_ctl_bytes());
-        if (int e = gn_zero_async(ctl->error, sizeof(ctl->error), st)) return e;
-    }
     // slot layout order == PartLayout order: W, b, w3, b3, w2, b2, w1, b1
     GradDst gd;
     gd.dst[0] = (float*)grads->odefunc_linear_weight; gd.dst[1] = (float*)grads->odefunc_linear_bias;

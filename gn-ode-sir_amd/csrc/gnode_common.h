@@ -91,6 +91,10 @@ void gnode_set_error(const char* fmt, ...);
 // caller captures the call into a HIP graph, and on this ROCm such nodes were not re-executed reliably on the second and later
 // replays (round 3: the trainer's replayed step summed stale gradient slots).  Kernel nodes replay in order.
 int gn_zero_async(void* p, size_t bytes, hipStream_t st);
+// several regions in ONE launch (each 4-byte aligned, a multiple of 4 bytes): the start-up zero-fills of a backward call are
+// launch latency, not bytes, on the small graphs the reference trains on
+struct GnZeroRegions { void* p[6]; size_t bytes[6]; int n; };
+int gn_zero_regions_async(const GnZeroRegions& r, hipStream_t st);
 
 // opt-in launch profiler (gnode_profile_enable): bracket a launch of `kind` with HIP events when it is sampled
 bool gn_prof_begin(int kind, hipStream_t st);

@@ -35,7 +35,8 @@ int gn_launch_tiny64(const gnode_graph_s* g, long rows, const float* Y0, const f
 // encoder + beta/gamma + trajectory point 0 + read-out at grid point 0 + projected R + Z_I(y_0) in one launch
 // ZI / ZI_alt: the two gather tables, each [rows + 1][64]: row `rows` is the table's ZERO ROW (written here)
 int gn_launch_prologue64(const float* x, const gnode_params* p, float* Y, float* beta, float* gamma, float* sol0, float* ZI,
-                         float* ZI_alt, float* PR, float* S0, float* I0, float* R0, long rows, hipStream_t st);
+                         float* ZI_alt, float* PR, float* S0, float* I0, float* R0, long rows, void* zero_ptr /* optional: a region this launch zero-fills too */,
+                         size_t zero_bytes, hipStream_t st);
 
 // H = 128 node MLP on the matrix cores (gnode_h128.hip)
 int gn_h128_set_attributes();   // once per device, from gnode_graph_create

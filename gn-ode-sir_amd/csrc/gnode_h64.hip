@@ -603,7 +603,9 @@ __global__ __launch_bounds__(256) void k_prologue64(const float* __restrict__ x,
                                                     float* __restrict__ sol0, float* __restrict__ ZI, float* __restrict__ ZI_alt,
                                                     float* __restrict__ PR,
                                                     float* __restrict__ S0, float* __restrict__ I0, float* __restrict__ R0,
-                                                    long rows) {
+                                                    long rows, uint32_t* __restrict__ zero_words, int n_zero_words) {
+    if (zero_words && blockIdx.x == 0)          // the control block of the persistent launch that follows (gnode_pers64.hip)
+        for (int i = threadIdx.x; i < n_zero_words; i += 256) zero_words[i] = 0u;
     if (blockIdx.x == 0 && threadIdx.x < 32) {            // the zero rows behind the two gather tables (k_step64)
         float* z = (threadIdx.x < 16 ? ZI : ZI_alt) + (size_t)rows * 64 + 4 * (threadIdx.x & 15);
         st4g(z, zero4());
@@ -670,11 +672,12 @@ __global__ __launch_bounds__(256) void k_prologue64(const float* __restrict__ x,
 }
 
 int gn_launch_prologue64(const float* x, const gnode_params* p, float* Y, float* beta, float* gamma, float* sol0, float* ZI,
-                         float* ZI_alt, float* PR, float* S0, float* I0, float* R0, long rows, hipStream_t st) {
+                         float* ZI_alt, float* PR, float* S0, float* I0, float* R0, long rows, void* zero_ptr, size_t zero_bytes, hipStream_t st) {
     const long ntiles = (rows + TILE_ROWS - 1) / TILE_ROWS;
     hipLaunchKernelGGL(k_prologue64, dim3((unsigned)std::min<long>(ntiles, 2048)), dim3(256), 0, st, x, p->linearS1_weight,
                        p->linearS1_bias, p->odefunc_linear_weight, p->odefunc_linear_bias, p->linear3_weight, p->linear3_bias,
-                       p->linearS2_weight, p->linearS2_bias, Y, beta, gamma, sol0, ZI, ZI_alt, PR, S0, I0, R0, rows);
+                       p->linearS2_weight, p->linearS2_bias, Y, beta, gamma, sol0, ZI, ZI_alt, PR, S0, I0, R0, rows, (uint32_t*)zero_ptr,
+                       (int)(zero_ptr ? zero_bytes / 4 : 0));
     GN_LAUNCH_CHECK();
     return 0;
 }

@@ -44,6 +44,27 @@ int gn_zero_async(void* p, size_t bytes, hipStream_t st) {
     GN_LAUNCH_CHECK();
     return 0;
 }
+__global__ __launch_bounds__(256) void k_zero_regions(GnZeroRegions r) {
+    uint32_t* p = (uint32_t*)r.p[blockIdx.y];
+    const size_t nwords = r.bytes[blockIdx.y] / 4;
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < nwords; i += stride) {
+        if (i + 4 <= nwords && ((uintptr_t)(p + i) & 15u) == 0) *reinterpret_cast<uint4*>(p + i) = make_uint4(0u, 0u, 0u, 0u);
+        else for (size_t j = i; j < nwords && j < i + 4; ++j) p[j] = 0u;
+    }
+}
+int gn_zero_regions_async(const GnZeroRegions& r, hipStream_t st) {
+    size_t mx = 0;
+    for (int k = 0; k < r.n; ++k) {
+        GN_CHECK_ARG(r.bytes[k] % 4 == 0 && ((uintptr_t)r.p[k] & 3u) == 0, "gn_zero_regions_async: unaligned region");
+        mx = std::max(mx, r.bytes[k]);
+    }
+    if (r.n <= 0 || mx == 0) return 0;
+    const unsigned gx = (unsigned)std::min<size_t>((mx / 16 + 255) / 256 + 1, 1024);
+    hipLaunchKernelGGL(k_zero_regions, dim3(gx, (unsigned)r.n), dim3(256), 0, st, r);
+    GN_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int gnode_version(void) { return 221; }   // 221: gnode_backward_status, persistent launches for hidden 8 / 16 / 32 (gnode_forward_path kind 3); 220: forward takes flags + reports what sol / keep carry (sol_info), backward checks it; persistent one-launch path for mid-size graphs; 200: workspace sizes take the graph handle (hub scratch is carved from the caller's workspace); 210: forward / backward take the optional kept-activation buffer
 
 // --------------------------------------------------------------------------- instrumentation
@@ -713,11 +734,15 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
     if (keep) { zi_cur = gn_keep_zi(keep, rows, 0); zi_nxt = gn_keep_zi(keep, rows, 1); }   // step k gathers table k, fills k+1
     // inference (no trajectory requested): R only feeds the read-out -> carry its 4-float projection
     float* PR = (h64 && !sol) ? prbuf : nullptr;
+    bool pre_zeroed_ctl = false;
     if (h64 && n_steps > 0) {
         // encoder, beta/gamma, trajectory point 0, read-out at grid point 0, projected R and Z_I(y_0): one launch
+        // (the persistent launch's control block is zeroed by the prologue's first workgroup: one launch less in front of it)
+        pre_zeroed_ctl = gn_forward_kind(g, rows, H, method, n_steps, out_rows_host ? n_out : G, sol != nullptr, flags, nullptr) == 2;
         if (int e = gn_launch_prologue64(x, p, Y, beta, gamma, sol, zi_cur, zi_nxt, PR, slot >= 0 ? S + (size_t)slot * rows : nullptr,
                                          slot >= 0 ? I + (size_t)slot * rows : nullptr,
-                                         slot >= 0 ? R + (size_t)slot * rows : nullptr, rows, st))
+                                         slot >= 0 ? R + (size_t)slot * rows : nullptr, rows,
+                                         pre_zeroed_ctl ? forward_ctl_ptr(workspace, rows, H, method) : nullptr, gn_pers64_ctl_bytes(), st))
             return e;
     } else {
         DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_encode<LPR>, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), 0, st, x,
@@ -737,7 +762,7 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         for (int k = 0; k < n_steps; ++k) slots[k] = out_slot(k + 1);
         const bool sampled = prof_begin(0, st);
         if (int e = gn_launch_pers64(g, plan, rows, Y, PR, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta,
-                                     gamma, dt_host, slots, n_steps, p, S, I, R, sol, keep, forward_ctl_ptr(workspace, rows, H, method), st))
+                                     gamma, dt_host, slots, n_steps, p, S, I, R, sol, keep, forward_ctl_ptr(workspace, rows, H, method), pre_zeroed_ctl, st))
             return e;
         if (sampled) prof_mark(0, st);
         return 0;

@@ -49,7 +49,7 @@ int gn_pers64_set_attributes();
 int gn_launch_pers64(const gnode_graph_s* g, const PersPlan& pl, long rows, const float* Y0, const float* PR0, float* Z0, float* Z1,
                      const float* W, const float* bias, const float* beta, const float* gamma, const float* dt_host,
                      const int* slot_host, int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol, float* keep,
-                     void* ctl, hipStream_t st);
+                     void* ctl, bool ctl_is_zero /* the caller's previous launch on this stream zero-filled it */, hipStream_t st);
 
 // adjoint sweep, intervals G-2 .. 1, in one persistent launch (gnode_pers64_bwd.hip)
 int gn_pers_bwd64_set_attributes();
@@ -57,4 +57,4 @@ bool gn_pers_bwd64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p
 int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, int G, float* Q0, float* Q1, const float* sol,
                          const float* keep, const float* W, const float* beta, const float* gamma, float* a, float* part,
                          const float* gS, const float* gI, const float* gR, const gnode_params* p, const float* dt_host,
-                         const int* slot_of_prev, void* ctl, int* slots, hipStream_t st);
+                         const int* slot_of_prev, void* ctl, bool ctl_is_zero, int* slots, hipStream_t st);

@@ -396,7 +396,7 @@ int gn_pers64_set_attributes() {
 int gn_launch_pers64(const gnode_graph_s* g, const PersPlan& pl, long rows, const float* Y0, const float* PR0, float* Z0, float* Z1,
                      const float* W, const float* bias, const float* beta, const float* gamma, const float* dt_host,
                      const int* slot_host, int n_steps, const gnode_params* p, float* S, float* I, float* R, float* sol, float* keep,
-                     void* ctl, hipStream_t st) {
+                     void* ctl, bool ctl_is_zero, hipStream_t st) {
     PersArgs a;
     const int vi = pl.nt == 1 ? 0 : pl.nt == 2 ? 1 : 2;
     const bool hubs = g->n_hub > 0;
@@ -409,7 +409,8 @@ int gn_launch_pers64(const gnode_graph_s* g, const PersPlan& pl, long rows, cons
     a.S = S; a.I = I; a.R = R; a.sol = sol; a.ctl = (PersCtl*)ctl;
     a.sched.n_steps = n_steps;
     for (int k = 0; k < n_steps; ++k) { a.sched.dt[k] = dt_host[k]; a.sched.slot[k] = (short)slot_host[k]; }
-    if (int e = gn_pers64_zero_ctl(ctl, st)) return e;     // tickets, flags, give-up word: zeroed before EVERY launch
+    if (!ctl_is_zero)                                      // tickets, flags, give-up word: zeroed before EVERY launch (by the prologue launch where there is one)
+        if (int e = gn_pers64_zero_ctl(ctl, st)) return e;
     const bool prj = PR0 != nullptr, sc1 = pl.span > 1;
     const dim3 grid((unsigned)(pl.n_xcc * pl.slots));
 #define PS_GO(P, N, S) { if (hubs) hipLaunchKernelGGL((k_pers64<P, N, S, true>), grid, dim3(256 * N), pers_lds_bytes(N, g->perslds[vi]), st, a); \

@@ -276,7 +276,7 @@ int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, 
                          const float* keep, const float* W, const float* beta, const float* gamma, float* a, float* part,
                          const float* gS, const float* gI, const float* gR, const gnode_params* p, const float* dt_host,
                          const int* slot_of_prev /* [G]: output row of grid point i-1 for interval i, or -1 */, void* ctl,
-                         int* slots, hipStream_t st) {
+                         bool ctl_is_zero, int* slots, hipStream_t st) {
     PersBwdArgs x;
     const int vi = pl.nt == 1 ? 0 : 1;
     const bool hubs = g->n_hub > 0;
@@ -295,7 +295,8 @@ int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, 
     // samples are independent: batches beyond what one resident grid holds run as consecutive launches of `concurrent` samples
     for (int b0 = 0; b0 < x.B; b0 += pl.concurrent) {
         x.b0 = b0;
-        if (int e = gn_pers64_zero_ctl(ctl, st)) return e;
+        if (!(ctl_is_zero && b0 == 0))
+            if (int e = gn_pers64_zero_ctl(ctl, st)) return e;
 #define PB_GO(N, S) { if (hubs) hipLaunchKernelGGL((k_pers_bwd64<N, S, true>), grid, dim3(256 * N), pers_bwd_lds_bytes(N, g->perslds[vi]), st, x); \
                       else hipLaunchKernelGGL((k_pers_bwd64<N, S, false>), grid, dim3(256 * N), pers_bwd_lds_bytes(N, 0), st, x); }
         if (pl.nt == 1) { if (sc1) PB_GO(1, true) else PB_GO(1, false) }

@@ -17,4 +17,4 @@ int gn_launch_persg(const gnode_graph_s* g, const PersgPlan& pl, long rows, int 
 int gn_launch_persg_bwd(const gnode_graph_s* g, const PersgPlan& pl, long rows, int H, int G, float* ZI0, float* ZI1, float* Q0, float* Q1,
                         const float* ZS0, const float* sol, const float* beta, const float* gamma, float* a_state, float* part,
                         const float* gS, const float* gI, const float* gR, const gnode_params* p, const float* dt_host,
-                        const int* slot_of_prev, void* ctl, hipStream_t st);
+                        const int* slot_of_prev, void* ctl, bool ctl_is_zero, hipStream_t st);

@@ -593,7 +593,7 @@ int gn_launch_persg(const gnode_graph_s* g, const PersgPlan& pl, long rows, int 
 int gn_launch_persg_bwd(const gnode_graph_s* g, const PersgPlan& pl, long rows, int H, int G, float* ZI0, float* ZI1, float* Q0, float* Q1,
                         const float* ZS0, const float* sol, const float* beta, const float* gamma, float* a_state, float* part,
                         const float* gS, const float* gI, const float* gR, const gnode_params* p, const float* dt_host,
-                        const int* slot_of_prev, void* ctl, hipStream_t st) {
+                        const int* slot_of_prev, void* ctl, bool ctl_is_zero, hipStream_t st) {
     PersgArgs a;
     persg_common(a, g, pl, rows, H, p, ctl);
     a.T0 = ZI0; a.T1 = ZI1; a.Q0 = Q0; a.Q1 = Q1; a.ZS0 = ZS0; a.sol = const_cast<float*>(sol); a.beta = beta; a.gamma = gamma;
@@ -601,7 +601,8 @@ int gn_launch_persg_bwd(const gnode_graph_s* g, const PersgPlan& pl, long rows, 
     a.sched.n_steps = G - 1;
     a.sched.dt[0] = 0.f; a.sched.slot[0] = -1;
     for (int i = 1; i <= G - 1; ++i) { a.sched.dt[i] = dt_host[i - 1]; a.sched.slot[i] = (short)slot_of_prev[i]; }
-    if (int e = gn_pers64_zero_ctl(ctl, st)) return e;
+    if (!ctl_is_zero)
+        if (int e = gn_pers64_zero_ctl(ctl, st)) return e;
     const dim3 grid((unsigned)pl.wgs);
     if (H == 8) hipLaunchKernelGGL(k_persg_bwd<2>, grid, dim3(64 * pl.nw), pl.lds, st, a);
     else if (H == 16) hipLaunchKernelGGL(k_persg_bwd<4>, grid, dim3(64 * pl.nw), pl.lds, st, a);
