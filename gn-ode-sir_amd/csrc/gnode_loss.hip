@@ -20,7 +20,7 @@
 template <typename YT>
 __global__ __launch_bounds__(256) void k_l1_loss(const float* __restrict__ S, const float* __restrict__ I,
                                                  const float* __restrict__ R, const YT* __restrict__ y, long rows, int T, int t0,
-                                                 int RB, double* __restrict__ partial, float* __restrict__ sgn) {
+                                                 int RB, double* __restrict__ partial, float* __restrict__ sgn, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     YT* yl = reinterpret_cast<YT*>(lds_raw);                       // [RB][T*3]
     __shared__ double red[256];
@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256) void k_l1_loss(const float* __restrict__ S, co
                 const YT* yr = yl + (size_t)r * T3 + 3 * t;
                 const YT d0 = (YT)S[o] - yr[0], d1 = (YT)I[o] - yr[1], d2 = (YT)R[o] - yr[2];
                 acc += (double)fabs(d0) + (double)fabs(d1) + (double)fabs(d2);
-                s0 = d0 > 0 ? 1.f : (d0 < 0 ? -1.f : 0.f);
-                s1 = d1 > 0 ? 1.f : (d1 < 0 ? -1.f : 0.f);
-                s2 = d2 > 0 ? 1.f : (d2 < 0 ? -1.f : 0.f);
+                s0 = d0 > 0 ? scale : (d0 < 0 ? -scale : 0.f);
+                s1 = d1 > 0 ? scale : (d1 < 0 ? -scale : 0.f);
+                s2 = d2 > 0 ? scale : (d2 < 0 ? -scale : 0.f);
             }
             if (sgn) {
                 const size_t plane = (size_t)T * rows;
@@ -82,6 +82,12 @@ extern "C" size_t gnode_l1_loss_workspace_bytes(void) { return gn_align(kLossGri
 extern "C" int gnode_l1_loss_f32(const float* S, const float* I, const float* R, const void* y, int32_t y_is_f64, int64_t rows,
                                  int32_t T, int32_t t0, double* loss_sum, float* sgn, void* workspace, size_t workspace_bytes,
                                  void* stream) {
+    return gnode_l1_loss_scaled_f32(S, I, R, y, y_is_f64, rows, T, t0, loss_sum, sgn, 1.0f, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gnode_l1_loss_scaled_f32(const float* S, const float* I, const float* R, const void* y, int32_t y_is_f64, int64_t rows,
+                                        int32_t T, int32_t t0, double* loss_sum, float* sgn, float sign_scale, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
     GN_CHECK_ARG(S && I && R && y && loss_sum && workspace, "gnode_l1_loss_f32: null pointer");
     GN_CHECK_ARG(rows > 0 && T > 0 && t0 >= 0 && t0 <= T, "gnode_l1_loss_f32: bad shape rows=%lld T=%d t0=%d", (long long)rows, T, t0);
     if (workspace_bytes < gnode_l1_loss_workspace_bytes()) {
@@ -99,10 +105,10 @@ extern "C" int gnode_l1_loss_f32(const float* S, const float* I, const float* R,
     double* partial = (double*)workspace;
     if (y_is_f64)
         hipLaunchKernelGGL(k_l1_loss<double>, dim3(grid), dim3(256), RB * per_row, st, S, I, R, (const double*)y, (long)rows, T, t0,
-                           RB, partial, sgn);
+                           RB, partial, sgn, sign_scale);
     else
         hipLaunchKernelGGL(k_l1_loss<float>, dim3(grid), dim3(256), RB * per_row, st, S, I, R, (const float*)y, (long)rows, T, t0, RB,
-                           partial, sgn);
+                           partial, sgn, sign_scale);
     GN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_l1_reduce, dim3(1), dim3(256), 0, st, partial, grid, loss_sum);
     GN_LAUNCH_CHECK();

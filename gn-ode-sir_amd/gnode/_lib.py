@@ -23,7 +23,7 @@ EXPORTS = [
     "gnode_sir_mc_philox", "gnode_sir_mc_philox_scan", "gnode_sir_mc_philox_counted", "gnode_sir_mc_coins",
     "gnode_dmp_workspace_bytes", "gnode_dmp_f32",
     "gnode_meanfield_workspace_bytes", "gnode_meanfield_f64",
-    "gnode_l1_loss_workspace_bytes", "gnode_l1_loss_f32",
+    "gnode_l1_loss_workspace_bytes", "gnode_l1_loss_f32", "gnode_l1_loss_scaled_f32",
     "gnode_profile_enable", "gnode_profile_read", "gnode_profile_read_kind",
 ]
 
@@ -89,6 +89,8 @@ def load():
     lib.gnode_l1_loss_workspace_bytes.restype = sz
     lib.gnode_l1_loss_f32.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, sz, vp]
     lib.gnode_l1_loss_f32.restype = C.c_int
+    lib.gnode_l1_loss_scaled_f32.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, C.c_float, vp, sz, vp]
+    lib.gnode_l1_loss_scaled_f32.restype = C.c_int
     lib.gnode_backward_workspace_bytes.argtypes = [vp, i64, i32]
     lib.gnode_backward_workspace_bytes.restype = sz
     lib.gnode_backward_f32.argtypes = [vp, vp, C.POINTER(Params), vp, i32, vp, i32, vp, vp, sz, vp, vp, vp,

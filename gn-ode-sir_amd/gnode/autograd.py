@@ -71,3 +71,15 @@ def l1_loss_sum(S, I, R, y, t0=1):
     """The reference's loss numerator (ode_nn_ngraph_sim.py:230-234): S, I, R are the model's [T, rows(, 1)] outputs,
     y the labels [rows, T, 3] (fp32 or fp64); returns a float64 scalar.  Divide by rows * (T - t0) * 3 for L1Loss's mean."""
     return _L1LossSum.apply(S, I, R, y, t0)
+
+
+def l1_loss_mean_backward(S, I, R, y, count, t0=1):
+    """loss.backward() for  loss = l1_loss_sum(S, I, R, y, t0) / count  (the trainer's step, ode_nn_ngraph_sim.py:234-236) without
+    the scalar graph in between: the loss kernel writes sign(pred - y) / count, which IS dloss/d(S, I, R), and the backward
+    of the model starts from it -- five tiny launches less per step (division, ones, division's backward, a cast, a multiply).
+    Returns the loss SUM (float64 device scalar), as l1_loss_sum does.  Bit-identical gradients: the scalar path multiplies
+    the signs by the same fp32(1 / count)."""
+    total, sgn = ops.l1_loss_sum(S, I, R, y, t0, want_sign=True, sign_scale=1.0 / float(count))
+    gs = sgn.view(3, *S.shape)
+    torch.autograd.backward([S, I, R], [gs[0], gs[1], gs[2]])
+    return total

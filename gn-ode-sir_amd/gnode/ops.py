@@ -202,9 +202,10 @@ def backward_status() -> int:
     return int(code.value)
 
 
-def l1_loss_sum(S: torch.Tensor, I: torch.Tensor, R: torch.Tensor, y: torch.Tensor, t0: int = 1, want_sign: bool = True):
+def l1_loss_sum(S: torch.Tensor, I: torch.Tensor, R: torch.Tensor, y: torch.Tensor, t0: int = 1, want_sign: bool = True, sign_scale: float = 1.0):
     """sum over rows, t >= t0, c of |pred_c[t, row] - y[row, t, c]| as a float64 device scalar, and (want_sign)
-    sign(pred - y) as fp32 [3, T, rows] -- the loss of ode_nn_ngraph_sim.py:230-234 and its gradient in one launch."""
+    sign(pred - y) * sign_scale as fp32 [3, T, rows] -- the loss of ode_nn_ngraph_sim.py:230-234 and its gradient in one launch
+    (sign_scale = 1 / element count gives L1Loss's mean gradient as it stands)."""
     lib = _lib.load()
     S, I, R = (_f32c(t.detach()) for t in (S, I, R))
     T = int(S.shape[0])
@@ -218,7 +219,7 @@ def l1_loss_sum(S: torch.Tensor, I: torch.Tensor, R: torch.Tensor, y: torch.Tens
     total = torch.empty((), dtype=torch.float64, device=dev)
     sgn = torch.empty((3, T, rows), dtype=torch.float32, device=dev) if want_sign else None
     ws = _workspace(lib.gnode_l1_loss_workspace_bytes(), dev)
-    _lib.check(lib.gnode_l1_loss_f32(_lib.ptr(S), _lib.ptr(I), _lib.ptr(R), _lib.ptr(y), int(y.dtype == torch.float64), rows, T,
-                                     int(t0), _lib.ptr(total), _lib.ptr(sgn) if sgn is not None else None, _lib.ptr(ws),
-                                     ws.numel(), _lib.stream_ptr()))
+    _lib.check(lib.gnode_l1_loss_scaled_f32(_lib.ptr(S), _lib.ptr(I), _lib.ptr(R), _lib.ptr(y), int(y.dtype == torch.float64), rows, T,
+                                            int(t0), _lib.ptr(total), _lib.ptr(sgn) if sgn is not None else None, float(sign_scale),
+                                            _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
     return total, sgn

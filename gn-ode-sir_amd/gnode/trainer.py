@@ -185,11 +185,13 @@ class Runner:
             idx = list(range(n_items))
         return [idx[i:i + batch_size] for i in range(0, n_items, batch_size)]
 
-    def _local(self, xs, ys, sel):
+    def _local(self, xs, ys, sel, as_lists=False):
         lo, hi = sharding.shard_range(len(sel), self.rank, self.world)
         mine = sel[lo:hi]
         if not mine:
             return None, None
+        if as_lists:                                 # HIP-graph replay: the samples are copied straight into the graph's static inputs
+            return [xs[j] for j in mine], [ys[j] for j in mine]
         x = torch.stack([xs[j] for j in mine]) if self.stack else torch.cat([xs[j] for j in mine], 0)
         y = torch.cat([ys[j] for j in mine], 0)
         # multi-graph batches: which graph each sample sits on (its marker, ode_nn_ngraphs.py:333) is read ONCE per sample, not
@@ -214,17 +216,36 @@ class Runner:
         from .autograd import l1_loss_sum
         return l1_loss_sum(S, I, R, y, 1)
 
-    def _graphed_backward(self, x, y, gcount):
-        """Replay (capturing on first use) forward + L1 + backward for this batch shape; returns the loss sum."""
-        key = (tuple(x.shape), tuple(y.shape), gcount)
+    def _loss_backward(self, x, y, gcount):
+        """forward + loss + backward of one batch (gradients of the element-mean L1 over `gcount` elements); returns the loss sum"""
+        if not self.stack and self._picks:
+            S, I, R = self.model(x, out_rows=self.rows, picks=self._picks)
+        else:
+            S, I, R = self.model(x, out_rows=self.rows)
+        from .autograd import l1_loss_mean_backward
+        return l1_loss_mean_backward(S, I, R, y, gcount, 1)
+
+    def _graphed_backward(self, x_list, y_list, gcount):
+        """Replay (capturing on first use) forward + L1 + backward for this batch shape; returns the loss sum.  x_list / y_list:
+        the batch's samples ([n, 3+H] / [n, T, 3] each); they are copied straight into the graph's static inputs (one copy per
+        tensor: stacking first would be a second one)."""
+        B, n = len(x_list), x_list[0].shape[0]
+        key = (B, tuple(x_list[0].shape), tuple(y_list[0].shape), y_list[0].dtype, gcount)
         ent = self._graphs.get(key)
+
+        def fill(xs, ys):
+            for b in range(B):
+                xs[b].copy_(x_list[b], non_blocking=True)
+                ys[b * n:(b + 1) * n].copy_(y_list[b], non_blocking=True)
+
         if ent is None:
-            xs, ys = torch.zeros_like(x), torch.zeros_like(y)
-            xs.copy_(x); ys.copy_(y)
+            xs = torch.zeros((B,) + tuple(x_list[0].shape), dtype=x_list[0].dtype, device=self.device)
+            ys = torch.zeros((B * n,) + tuple(y_list[0].shape[1:]), dtype=y_list[0].dtype, device=self.device)
+            fill(xs, ys)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                 # warm-up: allocates .grad, sets kernel attributes
-                (self._loss_sum(xs, ys) / gcount).backward()
+            with torch.cuda.stream(side):                 # warm-up: sets kernel attributes, sizes the allocator's pools
+                self._loss_backward(xs, ys, gcount)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             # the captured backward CREATES the gradient tensors (in the graph's pool: fixed addresses, rewritten by every
@@ -234,13 +255,11 @@ class Runner:
                 p.grad = None
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                ls = self._loss_sum(xs, ys)
-                (ls / gcount).backward()
-                ls_out = ls.detach()
+                ls_out = self._loss_backward(xs, ys, gcount).detach()
             ent = (graph, xs, ys, ls_out, [p.grad for p in params])
             self._graphs[key] = ent
         graph, xs, ys, ls_out, grads = ent
-        xs.copy_(x); ys.copy_(y)
+        fill(xs, ys)
         graph.replay()
         for p, g in zip(self.model.parameters(), grads):       # each batch shape's graph owns its gradient tensors
             p.grad = g
@@ -255,7 +274,7 @@ class Runner:
         T = ys[0].shape[1] if ys else 0
         for sel in self.batches(len(xs), batch_size, True, epoch):
             gcount = sum(ys[j].shape[0] for j in sel) * (T - 1) * 3       # elements of the GLOBAL batch
-            x, y = self._local(xs, ys, sel)
+            x, y = self._local(xs, ys, sel, as_lists=self.use_graphs)
             if not self.use_graphs:
                 self.opt.zero_grad(set_to_none=True)
             elif x is None:
@@ -266,9 +285,8 @@ class Runner:
                 t_fwd += time.time() - t0
             elif x is not None:
                 t0 = time.time()
-                ls = self._loss_sum(x, y)
+                ls = self._loss_backward(x, y, gcount)
                 t_fwd += time.time() - t0
-                (ls / gcount).backward()
                 tot_t += ls.detach().to(torch.float64)
             if self.collective:
                 for p in self.model.parameters():                        # ranks without samples contribute zeros

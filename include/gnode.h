@@ -286,6 +286,11 @@ size_t gnode_l1_loss_workspace_bytes(void);
 int gnode_l1_loss_f32(const float* S, const float* I, const float* R, const void* y, int32_t y_is_f64, int64_t rows,
                       int32_t T, int32_t t0, double* loss_sum, float* sgn, void* workspace, size_t workspace_bytes,
                       void* stream);
+/* The same with the signs already multiplied by `sign_scale` (e.g. 1 / element count: L1Loss's mean): sgn is then the loss
+ * gradient with respect to the outputs as it stands, and no scaling launch follows. */
+int gnode_l1_loss_scaled_f32(const float* S, const float* I, const float* R, const void* y, int32_t y_is_f64, int64_t rows,
+                             int32_t T, int32_t t0, double* loss_sum, float* sgn, float sign_scale, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ---- instrumentation -------------------------------------------------------
  * While enabled, every launch of the two step kernels (0: gather + SIR update +
