@@ -174,6 +174,57 @@ __global__ __launch_bounds__(256) void k_encode(const float* __restrict__ x, con
     }
 }
 
+// Everything before the first Euler step of the generic-H fused path in ONE launch: encoder (k_encode), read-out at grid
+// point 0 (k_readout) and Z_I(y_0) (k_mlp_generic's arithmetic in k_step_generic's lane-group form: same fma chain from the
+// bias, same sigmoid -> the same bits), plus the zero-fill of the persistent launch's control block when one follows.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_prologue_generic(const float* __restrict__ x, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, const float* __restrict__ w3,
+                                                          const float* __restrict__ b3, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, float* __restrict__ Y,
+                                                          float* __restrict__ beta, float* __restrict__ gamma,
+                                                          float* __restrict__ sol0, float* __restrict__ ZI, float* __restrict__ S0,
+                                                          float* __restrict__ I0, float* __restrict__ R0, long rows, int H,
+                                                          uint32_t* __restrict__ zero_words, int n_zero_words) {
+    extern __shared__ float Wt[];                 // [H][H] transposed: Wt[k][j] = W[j][k]
+    for (int idx = threadIdx.x; idx < H * H; idx += 256) Wt[(size_t)(idx % H) * H + idx / H] = W[idx];
+    if (zero_words && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_zero_words; i += 256) zero_words[i] = 0u;
+    __syncthreads();
+    const int sub = threadIdx.x % LPR;
+    const long r = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    const bool inrow = r < rows, active = 4 * sub < H, ok = inrow && active;     // (every lane stays: the mat-vec and the read-out shuffle)
+    const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 yS = z0, yI = z0, yR = z0;
+    const size_t slab = (size_t)rows * H, off = (size_t)(inrow ? r : 0) * H + 4 * sub;
+    if (ok) {
+        const float* xr = x + r * (3 + H);
+        const float s0 = xr[0], i0 = xr[1], r0 = xr[2];
+        const float4 w = ld4(w1 + 4 * sub), b = ld4(b1 + 4 * sub);
+        auto enc = [&](float v) {
+            return make_float4(fmaxf(fmaf(w.x, v, b.x), 0.f), fmaxf(fmaf(w.y, v, b.y), 0.f),
+                               fmaxf(fmaf(w.z, v, b.z), 0.f), fmaxf(fmaf(w.w, v, b.w), 0.f));
+        };
+        yS = enc(s0); yI = enc(i0); yR = enc(r0);
+        st4(Y + off, yS); st4(Y + slab + off, yI); st4(Y + 2 * slab + off, yR);
+        if (sub == 0) { beta[r] = xr[3]; gamma[r] = xr[4]; }
+        if (sol0) {
+            st4(sol0 + off, yS); st4(sol0 + slab + off, yI); st4(sol0 + 2 * slab + off, yR);
+            const float* bg = xr + 3 + 4 * sub;
+            st4(sol0 + 3 * slab + off, make_float4(bg[0], bg[1], bg[2], bg[3]));
+        }
+    }
+    if (S0) {
+        float pS, pI, pR;
+        readout_row<LPR>(yS, yI, yR, active, sub, H, w3, b3, w2, b2, pS, pI, pR);
+        if (sub == 0 && inrow) { S0[r] = pS; I0[r] = pI; R0[r] = pR; }
+    }
+    const float4 bias4 = active ? ld4(bias + 4 * sub) : z0;
+    const float4 zi = group_mlp<LPR>(yI, Wt, bias4, sub, active, H);
+    if (ok) st4(ZI + off, zi);
+}
+
 // --------------------------------------------------------------------------- K1: node MLP  Z = sigmoid(Y W^T + b)
 // Generic FMA path (any H % 4 == 0, H <= 128): W^T staged in LDS, one LPR-lane
 // group per row, each lane 4 output features.
@@ -744,6 +795,18 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
                                          slot >= 0 ? R + (size_t)slot * rows : nullptr, rows,
                                          pre_zeroed_ctl ? forward_ctl_ptr(workspace, rows, H, method) : nullptr, gn_pers64_ctl_bytes(), st))
             return e;
+    } else if (method == 0 && H < 128 && n_steps > 0) {
+        // generic-H fused path: encoder, read-out at grid point 0 and Z_I(y_0) in one launch (+ the persistent launch's control block)
+        pre_zeroed_ctl = gn_forward_kind(g, rows, H, method, n_steps, out_rows_host ? n_out : G, sol != nullptr, flags, nullptr) == 3;
+        DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_prologue_generic<LPR>, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256),
+                                             (size_t)H * H * sizeof(float), st, x, p->linearS1_weight, p->linearS1_bias,
+                                             p->odefunc_linear_weight, p->odefunc_linear_bias, p->linear3_weight, p->linear3_bias,
+                                             p->linearS2_weight, p->linearS2_bias, Y, beta, gamma, sol, zi_cur,
+                                             slot >= 0 ? S + (size_t)slot * rows : nullptr, slot >= 0 ? I + (size_t)slot * rows : nullptr,
+                                             slot >= 0 ? R + (size_t)slot * rows : nullptr, (long)rows, H,
+                                             pre_zeroed_ctl ? (uint32_t*)forward_ctl_ptr(workspace, rows, H, method) : nullptr,
+                                             (int)(gn_pers64_ctl_bytes() / 4)));
+        GN_LAUNCH_CHECK();
     } else {
         DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_encode<LPR>, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), 0, st, x,
                                              p->linearS1_weight, p->linearS1_bias, Y, beta, gamma, sol, (long)rows, H));
@@ -776,7 +839,7 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
         for (int k = 0; k < n_steps; ++k) slots[k] = out_slot(k + 1);
         const bool sampled = prof_begin(0, st);
         if (int e = gn_launch_persg(g, gp, rows, H, Y, zi_cur, zi_nxt, beta, gamma, dt_host, slots, n_steps, p, S, I, R, sol,
-                                    forward_ctl_ptr(workspace, rows, H, method), st))
+                                    forward_ctl_ptr(workspace, rows, H, method), pre_zeroed_ctl, st))
             return e;
         if (sampled) prof_mark(0, st);
         if (sol) {

@@ -575,13 +575,14 @@ static void persg_common(PersgArgs& a, const gnode_graph_s* g, const PersgPlan& 
 
 int gn_launch_persg(const gnode_graph_s* g, const PersgPlan& pl, long rows, int H, const float* Y0, float* Z0, float* Z1,
                     const float* beta, const float* gamma, const float* dt_host, const int* slot_host, int n_steps,
-                    const gnode_params* p, float* S, float* I, float* R, float* sol, void* ctl, hipStream_t st) {
+                    const gnode_params* p, float* S, float* I, float* R, float* sol, void* ctl, bool ctl_is_zero, hipStream_t st) {
     PersgArgs a;
     persg_common(a, g, pl, rows, H, p, ctl);
     a.Y0 = Y0; a.T0 = Z0; a.T1 = Z1; a.beta = beta; a.gamma = gamma; a.S = S; a.I = I; a.R = R; a.sol = sol;
     a.sched.n_steps = n_steps;
     for (int k = 0; k < n_steps; ++k) { a.sched.dt[k] = dt_host[k]; a.sched.slot[k] = (short)slot_host[k]; }
-    if (int e = gn_pers64_zero_ctl(ctl, st)) return e;             // flags and the give-up word: zeroed before EVERY launch
+    if (!ctl_is_zero)                                              // flags and the give-up word: zeroed before EVERY launch (by the prologue here)
+        if (int e = gn_pers64_zero_ctl(ctl, st)) return e;
     const dim3 grid((unsigned)pl.wgs);
     if (H == 8) hipLaunchKernelGGL(k_persg<2>, grid, dim3(64 * pl.nw), pl.lds, st, a);
     else if (H == 16) hipLaunchKernelGGL(k_persg<4>, grid, dim3(64 * pl.nw), pl.lds, st, a);
