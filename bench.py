@@ -102,7 +102,7 @@ def bench_train(lib, dev, n, m, B, H, maxTime, deltaT, reps):
     import scipy.sparse as sp
     import torch
     from gnode import ops, synth
-    from gnode.autograd import l1_loss_sum
+    from gnode.autograd import l1_loss_sum, l1_loss_mean_backward
     from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
     rp, ci = synth.er_csr(n, m, seed=0)
     nnz = int(ci.shape[0])
@@ -118,8 +118,7 @@ def bench_train(lib, dev, n, m, B, H, maxTime, deltaT, reps):
     def step():
         opt.zero_grad()
         S, I, R = model(x, out_rows=rows)
-        loss = l1_loss_sum(S, I, R, y, 1) / (B * n * (maxTime - 1) * 3)       # L1Loss over [:, 1:, :] (the trainer's loss op)
-        loss.backward()
+        loss = l1_loss_mean_backward(S, I, R, y, B * n * (maxTime - 1) * 3, 1)   # L1Loss over [:, 1:, :] and its backward, as the trainer runs them
         opt.step()
         return loss
 
@@ -184,7 +183,7 @@ def reference_fixture_gradient(dev):
     import scipy.sparse as sp
     import torch
     from gnode import ops, synth
-    from gnode.autograd import l1_loss_sum
+    from gnode.autograd import l1_loss_sum, l1_loss_mean_backward
     from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from labels import closed_form_labels
@@ -216,7 +215,7 @@ def bench_train_dist(lib, dev, dist, world, rank, backend):
     import scipy.sparse as sp
     import torch
     from gnode import ops, sharding, synth
-    from gnode.autograd import l1_loss_sum
+    from gnode.autograd import l1_loss_sum, l1_loss_mean_backward
     from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
     n, m, B, H, maxTime, deltaT = 1893, 13835, 8, 64, 30, 0.5
     rp, ci = synth.er_csr(n, m, seed=0)
@@ -272,7 +271,7 @@ def bench_train_dist_h8(lib, dev, dist, world, rank, backend):
     import torch
     from gnode import ops, sharding, synth
     from gnode import ode_nn_ngraphs as multi
-    from gnode.autograd import l1_loss_sum
+    from gnode.autograd import l1_loss_sum, l1_loss_mean_backward
     H, maxTime, deltaT = 8, 20, 0.5
     sizes = [(62, 159), (620, 2102), (1893, 13835), (2905, 15645), (7066, 100736)]
     csr = [synth.er_csr(n, m, seed=n) for n, m in sizes]
@@ -349,7 +348,7 @@ def bench_mid(lib, dev):
     import scipy.sparse as sp
     import torch
     from gnode import ops, synth
-    from gnode.autograd import l1_loss_sum
+    from gnode.autograd import l1_loss_sum, l1_loss_mean_backward
     from gnode.ode_nn_ngraph_sim import ODEBlock, ODEfunc
     out = {}
     H, maxTime, deltaT = 64, 30, 0.5
@@ -372,7 +371,7 @@ def bench_mid(lib, dev):
         def train():
             opt.zero_grad()
             S, I, R = model(x, out_rows=rows)
-            (l1_loss_sum(S, I, R, y, 1) / (n * (maxTime - 1) * 3)).backward()
+            l1_loss_mean_backward(S, I, R, y, n * (maxTime - 1) * 3, 1)      # the trainer's step (gnode/trainer.py): loss kernel writes dloss/d(S,I,R)
             opt.step()
 
         rec = {"n": n, "nnz": nnz, "longest_row": int(np.diff(rp).max()), "B": 1, "euler_steps": n_steps,
@@ -443,7 +442,7 @@ def bench_h8(lib, dev):
     import torch
     from gnode import ops, synth
     from gnode import ode_nn_ngraphs as multi
-    from gnode.autograd import l1_loss_sum
+    from gnode.autograd import l1_loss_sum, l1_loss_mean_backward
     H, maxTime, deltaT = 8, 20, 0.5                                   # monitorer-ngraphs.py:14,20: maxTime 20
     n_steps = len(ops.time_grid(maxTime, deltaT)) - 1
     rows = ops.subsample_rows(maxTime, deltaT)
@@ -477,7 +476,7 @@ def bench_h8(lib, dev):
         # were formed; known[0] = False: the markers are read off the batch on every forward (one host sync per step)
         opt.zero_grad()
         S, I, R = model(x, out_rows=rows, picks=picks_train if known[0] else None)
-        (l1_loss_sum(S, I, R, y, 1) / (tot * (maxTime - 1) * 3)).backward()
+        l1_loss_mean_backward(S, I, R, y, tot * (maxTime - 1) * 3, 1)
         opt.step()
 
     def measure():
