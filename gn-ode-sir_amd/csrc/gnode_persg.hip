@@ -5,8 +5,10 @@
 // launch-latency bound on such batches -- 22k rows x 32-byte rows is 0.7 MB of state, 14.9 / 27.8 us per step / interval
 // measured -- exactly where H = 64 stood before gnode_pers64.hip.  Same cure, simpler shape:
 //
-//   * ONE launch, one workgroup per CU (dynamic LDS > half of the CU's 160 KB), a workgroup owns G = 256 / LPR rows of one sample
-//     (128 at H = 8; the graph's row map deals hub rows round-robin, the others in natural order) and keeps their state in REGISTERS for every step / interval;
+//   * ONE launch, one workgroup per CU (dynamic LDS > half of the CU's 160 KB).  A workgroup is 1 .. 4 waves, a wave holds
+//     64 / LPR rows of one sample (32 at H = 8); the plan takes the FEWEST rows per workgroup that keeps the whole batch resident
+//     (gn_persg_plan: the busiest CU's gather is what a step waits for), the graph's row map deals the rows longest first in
+//     snake order (gn_persg_build).  A row's state stays in REGISTERS for every step / interval;
 //   * only the gather tables travel: Z_I (forward), Z_I and q (adjoint), double-buffered; the hand-off between steps is the
 //     measured form of MI355X_MICROARCH.md's table for groups that span XCDs -- every storing wave `s_waitcnt vmcnt(0)`,
 //     workgroup barrier, ONE lane publishes the workgroup's epoch flag; the consumers' wave 0 polls all flags, barrier, every
