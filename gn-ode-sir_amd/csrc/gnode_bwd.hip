@@ -1218,9 +1218,14 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         if (has_ctl) add(ctl_ptr, gn_pers64_ctl_bytes());
         if (int e = gn_zero_regions_async(zr, st)) return e;
     }
+    // small hidden sizes, batches that fit one resident grid: the whole sweep INCLUDING its start-up is one persistent launch
+    PersgPlan gp;
+    const bool gpersist = H <= 32 && n_steps >= 1 && !(flags & GNODE_FWD_PER_STEP) && gn_persg_plan(g, rows, H, n_steps, &gp);
+    if (!gpersist) {
     hipLaunchKernelGGL(k_extract_bg, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, sol + 3 * slab, (long)rows, H,
                        beta, gamma);
     GN_LAUNCH_CHECK();
+    }
 
     const int lpr = lpr_of(H), rpw = 256 / lpr;
     auto slot_of = [&](int gi) -> int {
@@ -1240,7 +1245,8 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         GN_LAUNCH_CHECK();
         return 0;
     };
-    if (int e = head(G - 1)) return e;
+    if (!gpersist)
+        if (int e = head(G - 1)) return e;
     const size_t mlp_lds = ((size_t)H * H + (size_t)4 * rpw * H) * sizeof(float);
     if (H == 64 && n_steps >= 1) {
         // one launch per interval: a[3] | Z_S | Z_I(0) | q(0) | Z_I(1) | q(1)  (Z_S is row-local, the gather tables ping-pong)
@@ -1332,17 +1338,17 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         float* ZS = Z; float* ZIb[2] = {Z + slab, dpre};
         float* Qb[2] = {q, dpre + slab};
         const float* yl = sol + (size_t)(G - 1) * 4 * slab;
-        if (int e = gn_launch_mlp_any(g, yl, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
-        hipLaunchKernelGGL(k_bwd_q, dim3(2048), dim3(256), 0, st, a, Z, beta, q, (long)rows, H);
-        GN_LAUNCH_CHECK();
+        if (!gpersist) {
+            if (int e = gn_launch_mlp_any(g, yl, p->odefunc_linear_weight, p->odefunc_linear_bias, Z, 2 * rows, H, st)) return e;
+            hipLaunchKernelGGL(k_bwd_q, dim3(2048), dim3(256), 0, st, a, Z, beta, q, (long)rows, H);
+            GN_LAUNCH_CHECK();
+        }
         const size_t fl = std::max((size_t)2 * H * H + (size_t)4 * rpw * H, (size_t)rpw * (4 * H + 12));
         const int grid = (int)std::min<long>(BWD_NWG, std::max<long>(1, (rows + rpw - 1) / rpw));
         // batches that fit one resident grid: every interval in ONE persistent launch (gnode_persg.hip)
-        PersgPlan gp;
-        const bool gpersist = !(flags & GNODE_FWD_PER_STEP) && gn_persg_plan(g, rows, H, n_steps, &gp);
         if (gpersist) {
             int slot_prev[128];
-            slot_prev[0] = -1;
+            slot_prev[0] = slot_of(G - 1);
             for (int j = 1; j <= G - 1; ++j) slot_prev[j] = slot_of(j - 1);
             const bool sampled = gn_prof_begin(2, st);
             if (int e = gn_launch_persg_bwd(g, gp, rows, H, G, ZIb[0], ZIb[1], Qb[0], Qb[1], ZS, sol, beta, gamma, a, part, gS, gI, gR, p,

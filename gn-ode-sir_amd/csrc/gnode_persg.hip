@@ -313,13 +313,6 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
     const int G = a.sched.n_steps + 1;
     float4 aS = z0, aI = z0, aR = z0, zs0 = z0, zi0 = z0, yS = z0, yI = z0;
     float bt = 0.f, gm = 0.f;
-    if (row.inrow) {
-        bt = a.beta[row.r]; gm = a.gamma[row.r];
-        aS = ld4(a.a + off); aI = ld4(a.a + slab + off); aR = ld4(a.a + 2 * slab + off);
-        zs0 = ld4(a.ZS0 + off); zi0 = ld4(a.T0 + off);
-        const float* Yl = a.sol + (size_t)(G - 1) * 4 * slab;
-        yS = ld4(Yl + off); yI = ld4(Yl + slab + off);
-    }
     const float4 bias4 = ld4(a.bias + 4 * sub);
     float4 w3v[4];
 #pragma unroll
@@ -328,6 +321,35 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { hacc.dw3[k] = z0; hacc.db3[k] = 0.f; hacc.dw2[k] = 0.f; }
     hacc.db2 = 0.f;
+    {
+        // The sweep's start-up, which used to be four launches (beta / gamma extraction, the head's VJP at the last grid point,
+        // Z(y_{G-1}), q): the adjoint starts at dL/dsol[G-1], the first gather tables are this workgroup's rows of Z_I(y_{G-1})
+        // and q = beta (a_I - a_S) Z_S(y_{G-1}), published under epoch 1 (every interval waits for its epoch, the first included).
+        const int slot_last = a.sched.slot[0];
+        float4 y[3] = {z0, z0, z0};
+        float gout[3] = {0.f, 0.f, 0.f};
+        if (row.inrow) {
+            const float4 bg = ld4(a.sol + 3 * slab + (size_t)row.r * H);          // sol[0]'s 4th slab: beta, gamma, ... (ode_nn_ngraph_sim.py:149-168)
+            bt = bg.x; gm = bg.y;
+            const float* Yl = a.sol + (size_t)(G - 1) * 4 * slab;
+            y[0] = ld4(Yl + off); y[1] = ld4(Yl + slab + off);
+            if (slot_last >= 0) {
+                y[2] = ld4(Yl + 2 * slab + off);
+                const size_t o = (size_t)slot_last * a.rows + row.r;
+                gout[0] = a.S[o]; gout[1] = a.I[o]; gout[2] = a.R[o];
+            }
+        }
+        if (slot_last >= 0) head_vjp64<LPR>(y, gout, w3v, a.b3, a.w2, a.b2, aS, aI, aR, hacc);
+        yS = y[0]; yI = y[1];
+        zs0 = group_mlp<LPR>(yS, L.Wt, bias4, sub, true, H);                       // (the start-up launch's arithmetic: bias first)
+        zi0 = group_mlp<LPR>(yI, L.Wt, bias4, sub, true, H);
+        if (row.inrow) {
+            pers_st<16>(zt[0], row.off_b, zi0);
+            pers_st<16>(qt[0], row.off_b, make_float4(bt * (aI.x - aS.x) * zs0.x, bt * (aI.y - aS.y) * zs0.y,
+                                                      bt * (aI.z - aS.z) * zs0.z, bt * (aI.w - aS.w) * zs0.w));
+        }
+        pg_publish(a.ctl, 1u);
+    }
     float accW[4][H];                    // gW rows 4 sub .. 4 sub + 3 (dt folded in), all H columns
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -354,7 +376,7 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
             }
         }
         PS_STAMP(0)
-        if (i < G - 1 && !pg_barrier(a.ctl, a.wgs, (unsigned)(G - 1 - i), L.meta)) return;
+        if (!pg_barrier(a.ctl, a.wgs, (unsigned)(G - i), L.meta)) return;
         PS_STAMP(1)
         float4 ai = z0, gq = z0;
         if (items > 0) {
@@ -399,7 +421,7 @@ __global__ __launch_bounds__(256) void k_persg_bwd(const PersgArgs a) {
                                                                 bt * (aI.z - aS.z) * zs.z, bt * (aI.w - aS.w) * zs.w));
             }
             PS_STAMP(4)
-            pg_publish(a.ctl, (unsigned)(G - i));
+            pg_publish(a.ctl, (unsigned)(G - i + 1));
             PS_STAMP(5)
         }
         // behind the flag: gW += dt dpre^T y (S and I parts), gb += dt dpre
@@ -602,7 +624,7 @@ int gn_launch_persg_bwd(const gnode_graph_s* g, const PersgPlan& pl, long rows, 
     a.T0 = ZI0; a.T1 = ZI1; a.Q0 = Q0; a.Q1 = Q1; a.ZS0 = ZS0; a.sol = const_cast<float*>(sol); a.beta = beta; a.gamma = gamma;
     a.a = a_state; a.part = part; a.S = const_cast<float*>(gS); a.I = const_cast<float*>(gI); a.R = const_cast<float*>(gR);
     a.sched.n_steps = G - 1;
-    a.sched.dt[0] = 0.f; a.sched.slot[0] = -1;
+    a.sched.dt[0] = 0.f; a.sched.slot[0] = (short)slot_of_prev[0];           // [0]: the output row of the LAST grid point (its head VJP starts the sweep)
     for (int i = 1; i <= G - 1; ++i) { a.sched.dt[i] = dt_host[i - 1]; a.sched.slot[i] = (short)slot_of_prev[i]; }
     if (!ctl_is_zero)
         if (int e = gn_pers64_zero_ctl(ctl, st)) return e;
