@@ -27,6 +27,7 @@
 // allocates nothing, synchronises nothing and keeps nothing in the handle, so it can be captured into a
 // hipGraph on first use and one handle serves several streams.
 #include "gnode_common.h"
+#include "gnode_gather.h"
 #include <algorithm>
 #include <vector>
 
@@ -50,6 +51,18 @@ __global__ __launch_bounds__(256) void k_hub_seg(const int* __restrict__ seg_lo,
     const float* t1 = T1 ? T1 + (size_t)b * n * H : nullptr;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
     const int lo = seg_lo[s], hi = seg_hi[s];
+    if (LPR <= 4) {
+        // small lane groups (H = 8 / 16: the multi-graph launcher's hidden 8): fetching ids LPR at a time makes a 32-edge segment
+        // 16 dependent round trips of 2 loads; every lane reads the ids itself instead and keeps 16 (8 per table) rows in flight
+        // (gnode_gather.h) -- the same ascending sums.  Chung-Lu 75k x 4 samples at H = 8: 76 -> 5x us per Euler step.
+        if (t1) gn_gather2<8>(col, lo, hi, t0, t1, H, sub, active, a0, a1);
+        else a0 = gn_gather1<16>(col, lo, hi, t0, H, sub, active);
+        if (!active) return;
+        const size_t o = ((size_t)b * n_seg + s) * H + 4 * sub;
+        hst4(P0 + o, a0);
+        if (t1) hst4(P1 + o, a1);
+        return;
+    }
     for (int e0 = lo; e0 < hi; e0 += LPR) {
         const int cnt = min(LPR, hi - e0);
         const int mine = (sub < cnt) ? col[e0 + sub] : 0;

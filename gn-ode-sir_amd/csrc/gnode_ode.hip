@@ -328,7 +328,9 @@ __global__ __launch_bounds__(256) void k_gather(const int* __restrict__ rowptr, 
 // structure as k_step64 -- gather, Z_S from Y_S, update, read-out, next step's Z_I -- with the node
 // MLP as a lane-group mat-vec: the row's H values live 4 per lane, x_k is broadcast inside the group
 // by shuffle and multiplied with W^T (staged in LDS, [k][j]).
-template <int LPR>
+// HUBS (compile time, as k_step64): graphs without long rows carry none of that code and none of its registers -- the hub branch
+// keeps 32 partial rows in flight at the small lane-group sizes (168 VGPRs against 120)
+template <int LPR, bool HUBS>
 __global__ __launch_bounds__(256) void k_step_generic(const int* __restrict__ rowptr, const int* __restrict__ col, int n,
                                                       long rows, int H, float* Y,
                                                       const float* __restrict__ ZI, float* __restrict__ ZI_next,
@@ -355,20 +357,26 @@ __global__ __launch_bounds__(256) void k_step_generic(const int* __restrict__ ro
     float4 yS = z0, yI = z0, yR = z0, zi = z0;
     if (active) { yS = ld4(Y + off); yI = ld4(Y + slab + off); yR = ld4(Y + 2 * slab + off); zi = ld4(ZI + off); }
     const float nb = -beta[r], gm = gamma[r];
-    const int hub = hubidx ? hubidx[node] : -1;
+    const int hub = HUBS ? hubidx[node] : -1;
     float4 ai;
-    if (hub >= 0) {
+    if (HUBS && hub >= 0) {
         // long rows: their 32-edge segments were summed by k_hub_seg; add the partials up in segment order (what a separate
         // reduction launch used to do -- at this size a launch costs as much as the step), 8 in flight
         ai = z0;
         const float* pp = HubP + (size_t)blockIdx.y * n_seg * H + 4 * sub;
         const int s1 = hub_seg_ptr[hub + 1];
-        for (int sg = hub_seg_ptr[hub]; sg < s1; sg += 8) {
-            float4 u[8];
+        // (one lane group walks a hub's partials: a 12 777-edge row is 400 of them, and at 8 in flight that single chain was 30 us of
+        //  a 76 us step at H = 8 -- 32 in flight for the small lane groups, which have the registers; same order, same bits)
+#ifndef GN_HUB_PF
+#define GN_HUB_PF 32
+#endif
+        constexpr int PF = LPR <= 4 ? GN_HUB_PF : 8;
+        for (int sg = hub_seg_ptr[hub]; sg < s1; sg += PF) {
+            float4 u[PF];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) u[q] = (active && sg + q < s1) ? ld4(pp + (size_t)(sg + q) * H) : z0;
+            for (int q = 0; q < PF; ++q) u[q] = (active && sg + q < s1) ? ld4(pp + (size_t)(sg + q) * H) : z0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { ai.x += u[q].x; ai.y += u[q].y; ai.z += u[q].z; ai.w += u[q].w; }
+            for (int q = 0; q < PF; ++q) { ai.x += u[q].x; ai.y += u[q].y; ai.z += u[q].z; ai.w += u[q].w; }
         }
     } else ai = gather_row<LPR>(rowptr, col, ZI + (size_t)base * H, node, sub, active, H);
     const float4 zs = group_mlp<LPR>(yS, Wt, bias4, sub, active, H);
@@ -896,7 +904,8 @@ extern "C" int gnode_forward_f32(gnode_graph_t g, const float* x, const gnode_pa
             const size_t lds = (size_t)H * H * sizeof(float);
             const bool sampled = prof_begin(0, st);
             // (H < 128 here: W^T is at most 61 KB of dynamic LDS, below the 64 KB that would need an attribute)
-            DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_step_generic<LPR>, grid, dim3(256), lds, st, g->rowptr, g->col, g->n, (long)rows, H,
+            const bool hubs = g->n_hub > 0;
+            DISPATCH_LPR(lpr, hipLaunchKernelGGL((hubs ? k_step_generic<LPR, true> : k_step_generic<LPR, false>), grid, dim3(256), lds, st, g->rowptr, g->col, g->n, (long)rows, H,
                                                  Ycur, zi_cur, zi_nxt, p->odefunc_linear_weight, p->odefunc_linear_bias, beta, gamma,
                                                  dt, p->linear3_weight, p->linear3_bias, p->linearS2_weight, p->linearS2_bias, out,
                                                  g->hubidx, HubP, g->hub_seg_ptr, g->n_seg));
