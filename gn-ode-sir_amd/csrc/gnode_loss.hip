@@ -99,7 +99,10 @@ extern "C" int gnode_l1_loss_scaled_f32(const float* S, const float* I, const fl
     // rows per block: as many as fit 48 KB of LDS (no attribute needed), at most 64, at least 1
     const size_t per_row = (size_t)T * 3 * el;
     GN_CHECK_ARG(per_row <= 48 * 1024, "gnode_l1_loss_f32: T=%d does not fit a label row into LDS", T);
-    const int RB = (int)std::max<size_t>(1, std::min<size_t>(64, (48 * 1024) / per_row));
+    // ... and few enough that a mid-size batch still spreads over the chip (1 893 rows in blocks of 64 are 30 workgroups staging
+    // 46 KB each: 13 us; in blocks of 4, 474 workgroups)
+    const size_t spread = std::max<size_t>(4, ((size_t)rows + kLossGrid - 1) / kLossGrid);
+    const int RB = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(64, spread), (48 * 1024) / per_row));
     const long nblocks = (rows + RB - 1) / RB;
     const int grid = (int)std::min<long>(kLossGrid, nblocks);
     double* partial = (double*)workspace;
