@@ -1253,10 +1253,6 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         float* ZS = Z; float* ZIb[2] = {Z + slab, dpre};     // (k_mlp64_q fills Z_S | Z_I element-contiguously)
         float* Qb[2] = {q, dpre + slab_b / sizeof(float)};
         // (the q tables' zero rows, Qb[k] + slab, were zero-filled by the call's first launch)
-        const long mt = (2 * rows + TILE_ROWS - 1) / TILE_ROWS;
-        hipLaunchKernelGGL(k_mlp64_q, dim3((unsigned)std::min<long>(mt, 1024)), dim3(256), 0, st, sol + (size_t)(G - 1) * 4 * slab,
-                           p->odefunc_linear_weight, p->odefunc_linear_bias, Z, a, beta, q, (long)rows);
-        GN_LAUNCH_CHECK();
         // 16-row tiles at 3 workgroups per CU (measured on the 75k graph, 4 samples: 32-row tiles at 3 / 2 per CU 481 / 548 us
         // per interval, the unfused three-launch form 563; 16-row tiles 451)
         // does this trajectory carry A Z_I(y_i) in its 4th slabs (gnode_forward_f32 wrote it: H = 64, not the one-launch path)?
@@ -1282,14 +1278,25 @@ extern "C" int gnode_backward_f32(gnode_graph_t g, const float* x, const gnode_p
         // mid-size graphs: intervals G-2 .. 1 over the kept activations in ONE persistent launch (gnode_pers64_bwd.hip)
         PersPlan pplan;
         const bool persist = keep && G >= 3 && !(flags & GNODE_FWD_PER_STEP) && gn_pers_bwd64_plan(g, rows / g->n, n_steps, &pplan);
+        // The last grid point emits nothing in the reference's use (get_sir_t_nodes_torch keeps the integer times, the grid ends
+        // half a step later): the adjoint is still ZERO through interval G-1 -- every product of that interval is zero -- and all
+        // it leaves is the head's VJP at grid point G-2 and the first q table.  The persistent sweep does that at its start
+        // (`fold`), and the two start-up launches (Z(y_{G-1}) + q, and the two-table interval kernel) do not run at all.
+        const bool fold = persist && slot_of(G - 1) < 0;
+        if (!fold) {
+            const long mt = (2 * rows + TILE_ROWS - 1) / TILE_ROWS;
+            hipLaunchKernelGGL(k_mlp64_q, dim3((unsigned)std::min<long>(mt, 1024)), dim3(256), 0, st, sol + (size_t)(G - 1) * 4 * slab,
+                               p->odefunc_linear_weight, p->odefunc_linear_bias, Z, a, beta, q, (long)rows);
+            GN_LAUNCH_CHECK();
+        }
         for (int i = G - 1; i >= 1; --i) {
-            if (persist && i == G - 2) {
+            if (persist && (i == G - 2 || fold)) {
                 int slot_prev[128];
-                for (int j = 1; j <= G - 2; ++j) slot_prev[j] = slot_of(j - 1);
+                for (int j = 1; j <= G - 1; ++j) slot_prev[j] = slot_of(j - 1);
                 int pslots = 0;
                 const bool sampled = gn_prof_begin(2, st);
                 if (int e = gn_launch_pers_bwd64(g, pplan, rows, G, Qb[0], Qb[1], sol, keep, p->odefunc_linear_weight, beta, gamma, a, part,
-                                                 gS, gI, gR, p, dt_host, slot_prev, ctl_ptr, true, &pslots, st))
+                                                 gS, gI, gR, p, dt_host, slot_prev, ctl_ptr, true, fold, &pslots, st))
                     return e;
                 if (sampled) gn_prof_end(2, st);
                 slots_used = std::max(slots_used, pslots);

@@ -57,4 +57,6 @@ bool gn_pers_bwd64_plan(const gnode_graph_s* g, long B, int n_steps, PersPlan* p
 int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, int G, float* Q0, float* Q1, const float* sol,
                          const float* keep, const float* W, const float* beta, const float* gamma, float* a, float* part,
                          const float* gS, const float* gI, const float* gR, const gnode_params* p, const float* dt_host,
-                         const int* slot_of_prev, void* ctl, bool ctl_is_zero, int* slots, hipStream_t st);
+                         const int* slot_of_prev, void* ctl, bool ctl_is_zero,
+                         bool fold /* the adjoint is zero through interval G-1 (last grid point not emitted): start there */,
+                         int* slots, hipStream_t st);

@@ -37,6 +37,7 @@ struct PersBwdArgs {
     const float* gS; const float* gI; const float* gR;
     const float* w3; const float* b3; const float* w2; const float* b2;
     PersCtl* ctl;
+    int fold;                            // 1: the sweep also covers interval G-1, whose adjoint is zero (last grid point not emitted)
     float dt[128];                       // dt[i]: step size of interval i (grid point i-1 -> i)
     short slot[128];                     // slot[i]: output row of grid point i-1, or -1
 };
@@ -138,8 +139,31 @@ __global__ __launch_bounds__(256 * NT) void k_pers_bwd64(const PersBwdArgs a) {
     };
     Pre pre;
     prefetch(G - 2, pre);
+    const int fold = a.fold;                               // 1: the sweep starts one interval early (see gnode_backward_f32), every epoch is one later
+    if (fold) {
+        // interval G-1 with a zero adjoint: only the head's VJP at grid point G-2 and the q row interval G-2 gathers remain
+        const int s = a.slot[G - 1];
+        if (s >= 0) {
+            float4 y[3];
+            float gout[3] = {0.f, 0.f, 0.f};
+            const float* sp = a.sol + (size_t)(G - 2) * 4 * slab;
+            y[0] = ld4so<true>(sp, off); y[1] = ld4so<true>(sp + slab, off); y[2] = ld4so<true>(sp + 2 * slab, off);
+            if (valid) { gout[0] = a.gS[(size_t)s * rows + row]; gout[1] = a.gI[(size_t)s * rows + row]; gout[2] = a.gR[(size_t)s * rows + row]; }
+            float4 w3v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w3v[q] = ld4g(a.w3 + q * 64 + 4 * sub);
+            head_vjp64(y, gout, w3v, a.b3, a.w2, a.b2, aS, aI, aR, hacc);
+        }
+        const float4 zsp = ld4so<true>(gn_keep_zs(a.keep, rows, G - 2), off);
+        if (valid) pers_st<STAUX>(pers_rsrc(a.Q[1], tbytes), off,
+                                  make_float4(bt * (aI.x - aS.x) * zsp.x, bt * (aI.y - aS.y) * zsp.y,
+                                              bt * (aI.z - aS.z) * zsp.z, bt * (aI.w - aS.w) * zsp.w));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flags + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (int i = G - 2; i >= 1; --i) {
-        const int k = G - 2 - i;                           // intervals done so far = epochs published
+        const int k = G - 2 - i + fold;                    // epochs published so far
         const int cur = (G - 1 - i) & 1;
         const float dt = a.dt[i];
         if (k > 0) {
@@ -276,7 +300,7 @@ int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, 
                          const float* keep, const float* W, const float* beta, const float* gamma, float* a, float* part,
                          const float* gS, const float* gI, const float* gR, const gnode_params* p, const float* dt_host,
                          const int* slot_of_prev /* [G]: output row of grid point i-1 for interval i, or -1 */, void* ctl,
-                         bool ctl_is_zero, int* slots, hipStream_t st) {
+                         bool ctl_is_zero, bool fold, int* slots, hipStream_t st) {
     PersBwdArgs x;
     const int vi = pl.nt == 1 ? 0 : 1;
     const bool hubs = g->n_hub > 0;
@@ -290,6 +314,8 @@ int gn_launch_pers_bwd64(const gnode_graph_s* g, const PersPlan& pl, long rows, 
     x.ctl = (PersCtl*)ctl;
     for (int i = 0; i < 128; ++i) { x.dt[i] = 0.f; x.slot[i] = -1; }
     for (int i = 1; i <= G - 2; ++i) { x.dt[i] = dt_host[i - 1]; x.slot[i] = (short)slot_of_prev[i]; }
+    x.fold = fold ? 1 : 0;
+    if (fold && G - 1 < 128) x.slot[G - 1] = (short)slot_of_prev[G - 1];      // the head's VJP at grid point G-2 belongs to interval G-1
     const bool sc1 = pl.span > 1;
     const dim3 grid((unsigned)(pl.n_xcc * pl.slots));
     // samples are independent: batches beyond what one resident grid holds run as consecutive launches of `concurrent` samples
